@@ -1,0 +1,216 @@
+/* pypore_qc.h -- C ABI of libpypore_qc.so: MI355X (gfx950) per-read QC statistics for `pypore seqstats`.
+ *
+ * The reference (rsemeraro/PyPore) is pure Python and has no FFI; the seam this library slots into is
+ * the task protocol of lib/seq_routines.py:18-37 (a callable per channel / per file whose result is
+ * merged into ChannelDict, :940-942, :1020-1022) and the ChannelDict data contract consumed by
+ * result_plotting (:572) and FastStats (:97).  Each entry point below cites the reference code it
+ * replaces.  Loaders (h5py / FASTQ) stay on the CPU and hand over reads packed as CSR.
+ *
+ * Conventions: every call returns 0 on success or a negative PPQC_E_* code; ppqc_last_error() gives a
+ * thread-local message; nothing throws across the ABI.  A context is bound to one GPU and must be
+ * driven by one thread at a time.  There is NO CPU fallback: without a usable HIP device every
+ * compute entry point fails with PPQC_E_NO_DEVICE.
+ */
+#ifndef PYPORE_QC_H
+#define PYPORE_QC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPQC_ABI_VERSION 1
+
+enum {
+    PPQC_OK = 0,
+    PPQC_E_INVALID = -1,   /* bad argument / config */
+    PPQC_E_NO_DEVICE = -2, /* no HIP device, or device index out of range */
+    PPQC_E_HIP = -3,       /* a HIP runtime call failed (message has the hipError string) */
+    PPQC_E_NOMEM = -4,
+    PPQC_E_STATE = -5,     /* call order violated (e.g. fetch before finalize) */
+    PPQC_E_RANGE = -6      /* input outside the documented range (e.g. time_mode 1 with a >2^32 s span) */
+};
+
+/* fixed-point scale of the error-probability sum: e[b] = round(2^52 * 10^(-(b-33)/10)) */
+#define PPQC_ERR_SHIFT 52
+
+/* sizes of the fixed tables */
+#define PPQC_N_TOTALS 16
+#define PPQC_N_LEN_LOG2 40
+#define PPQC_N_LEN_LIN 100
+#define PPQC_N_QHIST 8
+#define PPQC_N_GCHIST 20
+
+/* indices into ppqc_tables.totals */
+enum {
+    PPQC_TOT_N_READS = 0,    /* every read submitted */
+    PPQC_TOT_N_BASES = 1,    /* sum of lengths (fail-flagged reads count 0)                */
+    PPQC_TOT_N_FAIL = 2,     /* reads with mean_q < fail_q, regardless of mux ("true" fails) */
+    PPQC_TOT_N_GC = 3,
+    PPQC_TOT_N_N = 4,
+    PPQC_TOT_QSUM = 5,       /* sum of integer Phred scores (two's complement)             */
+    PPQC_TOT_N_BINNED = 6,   /* reads that reached the hour / channel x mux x hour tables  */
+    PPQC_TOT_BAD_CHANNEL = 7,/* channel outside 1..n_channels: counted here and in N_READS only */
+    PPQC_TOT_TIME_OOB = 8,   /* hour bin outside [0, n_time_bins): dropped from hour tables only */
+    PPQC_TOT_ZERO_LEN = 9,
+    PPQC_TOT_BAD_MUX = 10    /* mux outside 1..n_mux: in channel totals, not in mux/hour/fail tables
+                                (lib/fast5_reader.py:130-137 only visits mux '1'..'4') */
+};
+
+/* Hard-coded in the reference: 512 channels (lib/seq_routines.py:905-906), 4 muxes
+ * (lib/fast5_reader.py:130), 48 hourly bins (lib/seq_routines.py:99), fail below 7.0
+ * (lib/fast5_reader.py:136), Phred+33 (SeqIO 'fastq', lib/seq_routines.py:50). */
+typedef struct ppqc_config {
+    uint32_t struct_size;  /* = sizeof(ppqc_config); set by ppqc_config_default */
+    uint32_t n_channels;   /* 512 */
+    uint32_t n_mux;        /* 4 */
+    uint32_t n_time_bins;  /* 48 */
+    uint32_t bin_seconds;  /* 3600 */
+    uint32_t time_mode;    /* 0: bin = floor((t - ref + tz) / bin_seconds)
+                              1: reference quirk, lib/fast5_reader.py:117-126: hour of day of (t - ref + tz),
+                                 then per channel in start-time order every read from the first descent at
+                                 index >= 2 onwards gets +24 (needs bin_seconds == 3600) */
+    int32_t tz_offset_s;   /* local-zone offset the reference picks up through time.localtime (:118); 0 = UTC */
+    uint32_t reserved0;
+    int64_t ref_time_s;    /* RefTime / RefStart (lib/seq_routines.py:819-828, multi_read_fast5_reader.py:137) */
+    double fail_q;         /* 7.0 */
+    uint64_t max_reads_hint; /* per-read arrays are pre-sized to this (0 = grow on demand) */
+} ppqc_config;
+
+/* One CSR batch of reads (what lib/fast5_reader.py:36-71 / lib/multi_read_fast5_reader.py:89-119
+ * extract per read, and the FASTQ record of lib/fastqparser.py:7-16: bases = line 2, quals = line 4).
+ * offsets[0] must be 0 and offsets[n_reads] == n_bytes.  For ppqc_submit all pointers are host memory
+ * (ideally from ppqc_alloc_pinned); for ppqc_submit_device all are device memory, bases/quals 16-byte
+ * aligned.  A 16-byte aligned load may touch up to 15 bytes past n_bytes inside the same 16-byte granule. */
+typedef struct ppqc_batch {
+    uint64_t n_reads;
+    uint64_t n_bytes;
+    const uint8_t* bases;         /* ASCII, n_bytes */
+    const uint8_t* quals;         /* ASCII Phred+33, n_bytes */
+    const uint64_t* offsets;      /* n_reads + 1 */
+    const uint32_t* channel;      /* channel_number, 1-based (lib/fast5_reader.py:50) */
+    const uint8_t* mux;           /* start_mux (lib/fast5_reader.py:48) */
+    const int64_t* start_time_s;  /* mktime(parse(time_stamp)) whole seconds (lib/fast5_reader.py:66-67) */
+    const uint8_t* fail_flag;     /* optional (may be NULL): path contains 'fail' => len 0, q 6.99, gc 0
+                                     (lib/fast5_reader.py:37-40,52) */
+} ppqc_batch;
+
+/* Per-read results, caller-allocated SoA; any pointer may be NULL to skip that column. */
+typedef struct ppqc_per_read {
+    uint32_t* length;   /* offsets[i+1]-offsets[i]  (== sequence_length attr, lib/fast5_reader.py:55); 0 if flagged */
+    uint32_t* gc_count; /* G,C,S either case (Bio.SeqUtils.GC numerator, lib/fast5_reader.py:58) */
+    uint32_t* n_count;  /* N, n */
+    int64_t* qsum;      /* sum(byte) - 33*length */
+    double* mean_q;     /* -10*log10(S / (length * 2^52)); 0.0 for empty reads; 6.99 if flagged
+                           (ONT mean_qscore, the attribute read at lib/fast5_reader.py:56) */
+    uint64_t* err_hi;   /* S = err_hi * 2^32 + err_lo exactly; the halves are sums, not a canonical split */
+    uint64_t* err_lo;
+    uint8_t* flags;     /* bit0: fail (mean_q < fail_q), bit1: fail_flag was set */
+} ppqc_per_read;
+
+/* Run-level tables, caller-allocated (all uint64_t unless noted; NULL skips a table).
+ * Replaces the data part of parsing_func (lib/fast5_reader.py:127-158), FastStats
+ * (lib/seq_routines.py:97-144) and result_plotting / ChannelPlotter_f (:378-394, :507-514, :673-680). */
+typedef struct ppqc_tables {
+    uint64_t* totals;        /* PPQC_N_TOTALS */
+    uint64_t* len_hist_log2; /* PPQC_N_LEN_LOG2: bin 0 = len 0, bin k = [2^(k-1), 2^k) */
+    uint64_t* len_hist_lin;  /* PPQC_N_LEN_LIN bins of width lin_bin_width = max_len/100 + 1 */
+    uint64_t* q_hist;        /* PPQC_N_QHIST: 6+j <= mean_q < 7+j  (xbins 6..14 step 1, lib/seq_routines.py:234) */
+    uint64_t* gc_hist;       /* PPQC_N_GCHIST: 5k <= GC% < 5k+5, GC% > 0, 100 -> last (:136, :241) */
+    uint64_t* hour_reads;    /* n_time_bins (HoursDict[h][0], lib/seq_routines.py:103-108) */
+    uint64_t* hour_bases;    /* n_time_bins (HoursDict[h][1]) */
+    uint64_t* chan_reads;    /* n_channels  (ReadPerChannel,  lib/fast5_reader.py:128) */
+    uint64_t* chan_bases;    /* n_channels  (BasesPerChannel, :129) */
+    uint64_t* chan_fail;     /* n_channels  (FailedReads,     :136-137) */
+    uint64_t* cmh_reads;     /* [n_channels][n_mux][n_time_bins] (MuxProductivity, :138-145) */
+    uint64_t* cmh_bases;     /* same shape */
+    uint64_t* chan_min_len;  /* n_channels, INT64_MAX if the channel is empty (MaxMinvec, lib/seq_routines.py:132-133) */
+    uint64_t* chan_max_len;  /* n_channels */
+    uint64_t max_len;        /* out */
+    uint64_t min_pos_len;    /* out: smallest length > 0, INT64_MAX if none */
+    uint64_t lin_bin_width;  /* out */
+    uint64_t n50;            /* out: first length, descending, whose running sum c has 2c >= total */
+} ppqc_tables;
+
+/* Device-side view of the mergeable tables, for RCCL all-reduce through torch.distributed:
+ * sum_buf (n_sum u64, SUM), max_buf (n_max u64, MAX), min_buf (n_min u64, MIN; empty = INT64_MAX). */
+typedef struct ppqc_device_tables {
+    void* sum_buf; uint64_t n_sum;
+    void* max_buf; uint64_t n_max;   /* [0] = max_len, [1..] = chan_max_len */
+    void* min_buf; uint64_t n_min;   /* [0] = min_pos_len, [1..] = chan_min_len */
+    void* lengths; uint64_t n_lengths; /* uint32 per read (0 for bad-channel / flagged reads): N50 input */
+    /* offsets (in u64 elements) of each table inside sum_buf */
+    uint64_t off_totals, off_len_log2, off_len_lin, off_q_hist, off_gc_hist, off_hour_reads, off_hour_bases,
+        off_chan_reads, off_chan_bases, off_chan_fail, off_cmh_reads, off_cmh_bases;
+} ppqc_device_tables;
+
+/* GPU time of the stages of the most recent calls, measured with hipEvents on the library's stream. */
+typedef struct ppqc_timing {
+    double tile_kernel_ms_total;   /* per-read segmented-reduction kernel, summed since create / reset_timings */
+    uint64_t tile_kernel_launches;
+    uint64_t tile_kernel_bytes;    /* algorithmic bytes of those launches: 2*n_bytes + 50*n_reads */
+    double submit_ms_last;         /* whole last submit (H2D + kernels) */
+    double finalize_ms_last;       /* extremes + tables + sort + N50 of the last finalize */
+    double sort_ms_last;           /* radix sort + N50 part */
+} ppqc_timing;
+
+typedef struct ppqc_ctx ppqc_ctx;
+
+const char* ppqc_last_error(void);
+int ppqc_abi_version(void);
+int ppqc_device_count(int* n);
+int ppqc_config_default(ppqc_config* cfg);
+
+/* One context per GPU replaces the pool of Consumer processes of lib/seq_routines.py:916-923. */
+int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg);
+int ppqc_destroy(ppqc_ctx* ctx);
+/* Forget all reads submitted so far (a new run on the same context). */
+int ppqc_reset(ppqc_ctx* ctx);
+
+int ppqc_alloc_pinned(void** p, size_t bytes);
+int ppqc_free_pinned(void* p);
+
+/* Replaces the per-read work of get_content + the GC() call (lib/fast5_reader.py:36-71).  Asynchronous:
+ * H2D copies on one of two staging slots (double buffer), then the kernels; the host batch must stay
+ * alive until ppqc_sync.  slot is 0 or 1. */
+int ppqc_submit(ppqc_ctx* ctx, const ppqc_batch* host_batch, int slot);
+/* Same, for a batch already resident in HBM (kernel-only path). */
+int ppqc_submit_device(ppqc_ctx* ctx, const ppqc_batch* device_batch);
+int ppqc_sync(ppqc_ctx* ctx);
+
+int ppqc_n_reads(ppqc_ctx* ctx, uint64_t* n);
+/* Per-read records [first, first+n) (the ChrList entries of lib/fast5_reader.py:127, minus the hour). */
+int ppqc_read_stats(ppqc_ctx* ctx, const ppqc_per_read* out, uint64_t first, uint64_t n);
+/* Per-read hour bin as used by the tables (int32, -1 = not binned); valid after ppqc_finalize_tables. */
+int ppqc_read_hours(ppqc_ctx* ctx, int32_t* out, uint64_t first, uint64_t n);
+
+/* Run-level aggregation (replaces parsing_func's aggregation + the sums of FastStats), in phases so a
+ * multi-GPU caller can all-reduce between them:
+ *   ppqc_finalize_extremes -> [all-reduce MAX max_buf, MIN min_buf]
+ *   ppqc_finalize_tables   -> [all-reduce SUM sum_buf]
+ *   ppqc_finalize_n50(ctx, NULL, 0) or, multi-GPU, with the all-gathered device array of lengths
+ *   ppqc_fetch_tables
+ * ppqc_finalize runs all four for the single-GPU case. */
+int ppqc_finalize_extremes(ppqc_ctx* ctx);
+int ppqc_finalize_tables(ppqc_ctx* ctx);
+int ppqc_finalize_n50(ppqc_ctx* ctx, const uint32_t* device_lengths, uint64_t n);
+int ppqc_fetch_tables(ppqc_ctx* ctx, ppqc_tables* out);
+int ppqc_finalize(ppqc_ctx* ctx, ppqc_tables* out);
+int ppqc_device_tables_view(ppqc_ctx* ctx, ppqc_device_tables* out);
+
+int ppqc_timings(ppqc_ctx* ctx, ppqc_timing* out);
+int ppqc_reset_timings(ppqc_ctx* ctx);
+
+/* Stand-alone device utilities (no reference counterpart; used by bench.py and the tests).
+ * Hand-written LSD radix sort of n uint32 keys in device memory (ascending, in place). */
+int ppqc_sort_u32_device(ppqc_ctx* ctx, uint32_t* device_keys, uint64_t n);
+/* Counter-based synthetic read generator: fills device bases/quals for stream bytes [first, first+n). */
+int ppqc_synth_fill_device(ppqc_ctx* ctx, uint8_t* device_bases, uint8_t* device_quals, uint64_t first,
+                           uint64_t n, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYPORE_QC_H */

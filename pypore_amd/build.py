@@ -1,0 +1,35 @@
+"""Build libpypore_qc.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = ["ppqc_api.hip", "ppqc_tile.hip", "ppqc_tables.hip", "ppqc_sort.hip", "ppqc_synth.hip"]
+OUT = os.path.join(HERE, "libpypore_qc.so")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(HERE, "csrc", s) for s in SRC + ["ppqc_internal.hpp"]]
+    deps.append(os.path.join(HERE, "..", "include", "pypore_qc.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-o", OUT] + [os.path.join(HERE, "csrc", s) for s in SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,621 @@
+// Host side of libpypore_qc.so: the extern "C" entry points of include/pypore_qc.h.
+// Owns all device memory, one compute stream and two copy streams (double-buffered H2D) per context.
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "ppqc_internal.hpp"
+
+using namespace ppqc;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? PPQC_E_NOMEM : PPQC_E_HIP,                    \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+#define CHK(expr)                     \
+    do {                              \
+        int rc_ = (expr);             \
+        if (rc_ != PPQC_OK) return rc_; \
+    } while (0)
+
+namespace {
+
+struct Slot {   // device staging for one host batch
+    uint8_t *bases = nullptr, *quals = nullptr, *mux = nullptr, *ff = nullptr;
+    uint64_t* offsets = nullptr;
+    uint32_t* channel = nullptr;
+    int64_t* time = nullptr;
+    uint64_t cap_bytes = 0, cap_reads = 0;
+    hipEvent_t copied = nullptr, done = nullptr;
+    bool busy = false;
+};
+
+struct EvPair {
+    hipEvent_t a, b;
+    uint64_t bytes;
+};
+
+}  // namespace
+
+struct ppqc_ctx {
+    int device = 0, n_cu = 256;
+    ppqc_config cfg{};
+    TableParams tp{};
+    hipStream_t stream = nullptr, copy[2] = {nullptr, nullptr};
+    uint64_t* lut_dev = nullptr;
+
+    ReadArrays ra{};
+    uint64_t n_reads = 0, cap_reads = 0;
+
+    Partial *head = nullptr, *tail = nullptr;
+    uint64_t cap_tiles = 0;
+
+    Slot slot[2];
+
+    uint64_t *sum_buf = nullptr, *max_buf = nullptr, *min_buf = nullptr, *n50_out = nullptr;
+    int64_t* tminmax = nullptr;
+    int state = 0;   // 0 reads only, 1 extremes done, 2 tables done, 3 n50 done
+    uint64_t n50 = 0;
+
+    // sort / mode-1 scratch
+    uint32_t *sk32 = nullptr, *sk32_tmp = nullptr, *counts = nullptr, *vals = nullptr, *vals_tmp = nullptr;
+    uint64_t *sk64 = nullptr, *sk64_tmp = nullptr, *n50_blocks = nullptr;
+    uint32_t *chan_start = nullptr, *first_desc = nullptr;
+    uint64_t cap_sort32 = 0, cap_sort64 = 0;
+
+    std::vector<EvPair> pending;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
+    ppqc_timing timing{};
+};
+
+static hipEvent_t get_event(ppqc_ctx* c) {
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+template <typename T>
+static int grow(T** p, uint64_t old_n, uint64_t new_cap, hipStream_t s) {
+    T* q = nullptr;
+    HIPCHK(hipMalloc((void**)&q, new_cap * sizeof(T) + 64));
+    if (*p && old_n) HIPCHK(hipMemcpyAsync(q, *p, old_n * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (*p) {
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipFree(*p));
+    }
+    *p = q;
+    return PPQC_OK;
+}
+
+static int ensure_reads(ppqc_ctx* c, uint64_t need) {
+    if (need <= c->cap_reads) return PPQC_OK;
+    uint64_t cap = c->cap_reads ? c->cap_reads * 2 : 1024;
+    if (cap < need) cap = need;
+    const uint64_t n = c->n_reads;
+    hipStream_t s = c->stream;
+    ReadArrays& r = c->ra;
+    CHK(grow(&r.rec_cnt, 0, cap, s)); CHK(grow(&r.rec_hi, 0, cap, s)); CHK(grow(&r.rec_lo, 0, cap, s));
+    CHK(grow(&r.len, n, cap, s)); CHK(grow(&r.gc, n, cap, s)); CHK(grow(&r.nn, n, cap, s));
+    CHK(grow(&r.qsum, n, cap, s)); CHK(grow(&r.mean_q, n, cap, s));
+    CHK(grow(&r.err_hi, n, cap, s)); CHK(grow(&r.err_lo, n, cap, s)); CHK(grow(&r.flags, n, cap, s));
+    CHK(grow(&r.channel, n, cap, s)); CHK(grow(&r.mux, n, cap, s)); CHK(grow(&r.time, n, cap, s));
+    CHK(grow(&r.hour, 0, cap, s)); CHK(grow(&r.lens32, 0, cap, s));
+    c->cap_reads = cap;
+    return PPQC_OK;
+}
+
+static int ensure_tiles(ppqc_ctx* c, uint64_t n_tiles) {
+    if (n_tiles <= c->cap_tiles) return PPQC_OK;
+    uint64_t cap = c->cap_tiles ? c->cap_tiles * 2 : 1024;
+    if (cap < n_tiles) cap = n_tiles;
+    CHK(grow(&c->head, 0, cap, c->stream));
+    CHK(grow(&c->tail, 0, cap, c->stream));
+    c->cap_tiles = cap;
+    return PPQC_OK;
+}
+
+static int ensure_sort32(ppqc_ctx* c, uint64_t n) {
+    if (n <= c->cap_sort32) return PPQC_OK;
+    uint64_t cap = n + n / 4 + 1024;
+    CHK(grow(&c->sk32, 0, cap, c->stream));
+    CHK(grow(&c->sk32_tmp, 0, cap, c->stream));
+    CHK(grow(&c->counts, 0, sort_count_words(cap) + 1024, c->stream));
+    CHK(grow(&c->n50_blocks, 0, n50_block_words(cap), c->stream));
+    c->cap_sort32 = cap;
+    return PPQC_OK;
+}
+
+static int ensure_sort64(ppqc_ctx* c, uint64_t n) {
+    CHK(ensure_sort32(c, n));
+    if (n <= c->cap_sort64) return PPQC_OK;
+    uint64_t cap = n + n / 4 + 1024;
+    CHK(grow(&c->sk64, 0, cap, c->stream));
+    CHK(grow(&c->sk64_tmp, 0, cap, c->stream));
+    CHK(grow(&c->vals, 0, cap, c->stream));
+    CHK(grow(&c->vals_tmp, 0, cap, c->stream));
+    c->cap_sort64 = cap;
+    return PPQC_OK;
+}
+
+static uint64_t q_threshold(double q) { return (uint64_t)llrint(ldexp(pow(10.0, -q / 10.0), PPQC_ERR_SHIFT)); }
+
+static void make_layout(const ppqc_config& cfg, TableLayout* l) {
+    l->n_channels = cfg.n_channels; l->n_mux = cfg.n_mux; l->n_time_bins = cfg.n_time_bins;
+    uint64_t o = 0;
+    l->off_totals = o; o += PPQC_N_TOTALS;
+    l->off_len_log2 = o; o += PPQC_N_LEN_LOG2;
+    l->off_len_lin = o; o += PPQC_N_LEN_LIN;
+    l->off_q_hist = o; o += PPQC_N_QHIST;
+    l->off_gc_hist = o; o += PPQC_N_GCHIST;
+    l->off_hour_reads = o; o += cfg.n_time_bins;
+    l->off_hour_bases = o; o += cfg.n_time_bins;
+    l->off_chan_reads = o; o += cfg.n_channels;
+    l->off_chan_bases = o; o += cfg.n_channels;
+    l->off_chan_fail = o; o += cfg.n_channels;
+    const uint64_t cells = (uint64_t)cfg.n_channels * cfg.n_mux * cfg.n_time_bins;
+    l->off_cmh_reads = o; o += cells;
+    l->off_cmh_bases = o; o += cells;
+    l->n_sum = o;
+}
+
+template <typename T>
+static int slot_grow(T** p, uint64_t n) {
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr;
+    HIPCHK(hipMalloc((void**)p, n * sizeof(T) + 64));
+    return PPQC_OK;
+}
+
+extern "C" {
+
+const char* ppqc_last_error(void) { return g_err.c_str(); }
+int ppqc_abi_version(void) { return PPQC_ABI_VERSION; }
+
+int ppqc_device_count(int* n) {
+    if (!n) return fail(PPQC_E_INVALID, "null argument");
+    int k = 0;
+    hipError_t e = hipGetDeviceCount(&k);
+    if (e != hipSuccess) { *n = 0; return fail(PPQC_E_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *n = k;
+    return PPQC_OK;
+}
+
+int ppqc_config_default(ppqc_config* cfg) {
+    if (!cfg) return fail(PPQC_E_INVALID, "null argument");
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (uint32_t)sizeof(*cfg);
+    cfg->n_channels = 512; cfg->n_mux = 4; cfg->n_time_bins = 48; cfg->bin_seconds = 3600;
+    cfg->time_mode = 0; cfg->tz_offset_s = 0; cfg->ref_time_s = 0; cfg->fail_q = 7.0; cfg->max_reads_hint = 0;
+    return PPQC_OK;
+}
+
+int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
+    if (!out || !cfg) return fail(PPQC_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(ppqc_config)) return fail(PPQC_E_INVALID, "ppqc_config.struct_size mismatch");
+    if (cfg->n_channels == 0 || cfg->n_channels > (1u << 20) || cfg->n_mux == 0 || cfg->n_mux > 255 ||
+        cfg->n_time_bins == 0 || cfg->n_time_bins > 4096 || cfg->bin_seconds == 0 || cfg->time_mode > 1)
+        return fail(PPQC_E_INVALID, "config out of range");
+    if (cfg->time_mode == 1 && cfg->bin_seconds != 3600)
+        return fail(PPQC_E_INVALID, "time_mode 1 (reference hour-of-day quirk) needs bin_seconds == 3600");
+    if (!(cfg->fail_q >= 0.0 && cfg->fail_q <= 93.0)) return fail(PPQC_E_INVALID, "fail_q out of range");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(PPQC_E_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(PPQC_E_NO_DEVICE, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    ppqc_ctx* c = new ppqc_ctx();
+    c->device = device;
+    c->cfg = *cfg;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipStreamCreateWithFlags(&c->copy[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->slot[i].copied, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->slot[i].done, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreate(&c->ev_t0)); HIPCHK(hipEventCreate(&c->ev_t1));
+    HIPCHK(hipEventCreate(&c->ev_s0)); HIPCHK(hipEventCreate(&c->ev_s1));
+
+    // error-probability LUT: e[b] = round(2^52 * 10^(-q/10)), q = clamp(b - 33, 0, 93)
+    uint64_t lut[256];
+    for (int b = 0; b < 256; ++b) {
+        int q = b - 33;
+        q = q < 0 ? 0 : (q > 93 ? 93 : q);
+        lut[b] = (uint64_t)llrint(ldexp(pow(10.0, -(double)q / 10.0), PPQC_ERR_SHIFT));
+    }
+    HIPCHK(hipMalloc((void**)&c->lut_dev, sizeof(lut)));
+    HIPCHK(hipMemcpy(c->lut_dev, lut, sizeof(lut), hipMemcpyHostToDevice));
+
+    TableParams& tp = c->tp;
+    make_layout(*cfg, &tp.lay);
+    tp.bin_seconds = cfg->bin_seconds; tp.time_mode = cfg->time_mode; tp.tz_offset_s = cfg->tz_offset_s;
+    tp.ref_time_s = cfg->ref_time_s; tp.fail_q = cfg->fail_q; tp.thr_fail = q_threshold(cfg->fail_q);
+    for (int j = 0; j <= PPQC_N_QHIST; ++j) tp.thr_q[j] = q_threshold(6.0 + j);
+
+    HIPCHK(hipMalloc((void**)&c->sum_buf, tp.lay.n_sum * 8));
+    HIPCHK(hipMalloc((void**)&c->max_buf, (1 + (uint64_t)cfg->n_channels) * 8));
+    HIPCHK(hipMalloc((void**)&c->min_buf, (1 + (uint64_t)cfg->n_channels) * 8));
+    HIPCHK(hipMalloc((void**)&c->tminmax, 16));
+    HIPCHK(hipMalloc((void**)&c->n50_out, 16));
+    HIPCHK(hipMalloc((void**)&c->chan_start, (uint64_t)cfg->n_channels * 4 + 64));
+    HIPCHK(hipMalloc((void**)&c->first_desc, (uint64_t)cfg->n_channels * 4 + 64));
+    if (cfg->max_reads_hint) CHK(ensure_reads(c, cfg->max_reads_hint));
+    *out = c;
+    return PPQC_OK;
+}
+
+int ppqc_destroy(ppqc_ctx* c) {
+    if (!c) return PPQC_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    ReadArrays& r = c->ra;
+    void* ptrs[] = {r.rec_cnt, r.rec_hi, r.rec_lo, r.len, r.gc, r.nn, r.qsum, r.mean_q, r.err_hi, r.err_lo, r.flags,
+                    r.channel, r.mux, r.time, r.hour, r.lens32, c->head, c->tail, c->sum_buf, c->max_buf, c->min_buf,
+                    c->tminmax, c->n50_out, c->sk32, c->sk32_tmp, c->counts, c->vals, c->vals_tmp, c->sk64,
+                    c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i) {
+        Slot& s = c->slot[i];
+        void* sp[] = {s.bases, s.quals, s.mux, s.ff, s.offsets, s.channel, s.time};
+        for (void* p : sp) if (p) (void)hipFree(p);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (c->copy[i]) (void)hipStreamDestroy(c->copy[i]);
+    }
+    for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    hipEvent_t evs[] = {c->ev_t0, c->ev_t1, c->ev_s0, c->ev_s1};
+    for (auto e : evs) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PPQC_OK;
+}
+
+int ppqc_reset(ppqc_ctx* c) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->n_reads = 0;
+    c->state = 0;
+    c->n50 = 0;
+    return PPQC_OK;
+}
+
+int ppqc_alloc_pinned(void** p, size_t bytes) {
+    if (!p) return fail(PPQC_E_INVALID, "null argument");
+    HIPCHK(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+    return PPQC_OK;
+}
+int ppqc_free_pinned(void* p) {
+    if (p) HIPCHK(hipHostFree(p));
+    return PPQC_OK;
+}
+
+// Enqueue the per-read kernels for a batch whose arrays are all in device memory.
+static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
+    const uint64_t R = b->n_reads;
+    CHK(ensure_reads(c, c->n_reads + R));
+    const uint64_t n_tiles = (b->n_bytes + kTile - 1) / kTile;
+    CHK(ensure_tiles(c, n_tiles));
+    const uint64_t base = c->n_reads;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(c->ra.channel + base, b->channel, R * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->ra.mux + base, b->mux, R, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->ra.time + base, b->start_time_s, R * 8, hipMemcpyDeviceToDevice, s));
+    BatchView v{b->bases, b->quals, b->offsets, R, b->n_bytes, b->fail_flag};
+    EvPair ev{get_event(c), get_event(c), 2 * b->n_bytes + 50 * R};
+    if (!ev.a || !ev.b) return fail(PPQC_E_HIP, "hipEventCreate failed");
+    HIPCHK(hipEventRecord(ev.a, s));
+    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->n_cu, s));
+    HIPCHK(hipEventRecord(ev.b, s));
+    c->pending.push_back(ev);
+    HIPCHK(launch_finalize_reads(v, c->ra, base, c->head, c->tail, c->tp.thr_fail, c->tp.fail_q, s));
+    c->n_reads += R;
+    c->state = 0;
+    return PPQC_OK;
+}
+
+static int check_batch(const ppqc_batch* b) {
+    if (!b) return fail(PPQC_E_INVALID, "null batch");
+    if (b->n_reads >= (1ull << 32)) return fail(PPQC_E_RANGE, "more than 2^32-1 reads in one batch");
+    if (b->n_reads && (!b->offsets || !b->channel || !b->mux || !b->start_time_s))
+        return fail(PPQC_E_INVALID, "null metadata pointer");
+    if (b->n_bytes && (!b->bases || !b->quals)) return fail(PPQC_E_INVALID, "null bases/quals pointer");
+    if (b->n_reads == 0 && b->n_bytes != 0) return fail(PPQC_E_INVALID, "bytes without reads");
+    return PPQC_OK;
+}
+
+int ppqc_submit_device(ppqc_ctx* c, const ppqc_batch* b) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    CHK(check_batch(b));
+    if (b->n_reads == 0) return PPQC_OK;
+    if (((uintptr_t)b->bases & 15) || ((uintptr_t)b->quals & 15))
+        return fail(PPQC_E_INVALID, "device bases/quals must be 16-byte aligned");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev_s0, c->stream));
+    CHK(run_batch(c, b));
+    HIPCHK(hipEventRecord(c->ev_s1, c->stream));
+    return PPQC_OK;
+}
+
+int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    CHK(check_batch(b));
+    if (si < 0 || si > 1) return fail(PPQC_E_INVALID, "slot must be 0 or 1");
+    const uint64_t R = b->n_reads;
+    if (R == 0) return PPQC_OK;
+    // host-side validation of the CSR (the reference would fail inside the worker on a malformed read instead)
+    if (b->offsets[0] != 0) return fail(PPQC_E_INVALID, "offsets[0] must be 0");
+    for (uint64_t i = 0; i < R; ++i) {
+        if (b->offsets[i + 1] < b->offsets[i]) return fail(PPQC_E_INVALID, "offsets not monotone");
+        if (b->offsets[i + 1] - b->offsets[i] >= (1ull << 32)) return fail(PPQC_E_RANGE, "read longer than 2^32-1");
+    }
+    if (b->offsets[R] != b->n_bytes) return fail(PPQC_E_INVALID, "offsets[n_reads] != n_bytes");
+    HIPCHK(hipSetDevice(c->device));
+    Slot& s = c->slot[si];
+    if (s.busy) { HIPCHK(hipEventSynchronize(s.done)); s.busy = false; }
+    if (b->n_bytes > s.cap_bytes) {
+        const uint64_t cap = b->n_bytes + b->n_bytes / 4 + 4096;
+        CHK(slot_grow(&s.bases, cap)); CHK(slot_grow(&s.quals, cap));
+        s.cap_bytes = cap;
+    }
+    if (R > s.cap_reads) {
+        const uint64_t cap = R + R / 4 + 64;
+        CHK(slot_grow(&s.offsets, cap + 1)); CHK(slot_grow(&s.channel, cap)); CHK(slot_grow(&s.mux, cap));
+        CHK(slot_grow(&s.time, cap)); CHK(slot_grow(&s.ff, cap));
+        s.cap_reads = cap;
+    }
+    hipStream_t cs = c->copy[si];
+    HIPCHK(hipEventRecord(c->ev_s0, c->stream));
+    if (b->n_bytes) {
+        HIPCHK(hipMemcpyAsync(s.bases, b->bases, b->n_bytes, hipMemcpyHostToDevice, cs));
+        HIPCHK(hipMemcpyAsync(s.quals, b->quals, b->n_bytes, hipMemcpyHostToDevice, cs));
+    }
+    HIPCHK(hipMemcpyAsync(s.offsets, b->offsets, (R + 1) * 8, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(s.channel, b->channel, R * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(s.mux, b->mux, R, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(s.time, b->start_time_s, R * 8, hipMemcpyHostToDevice, cs));
+    if (b->fail_flag) HIPCHK(hipMemcpyAsync(s.ff, b->fail_flag, R, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipEventRecord(s.copied, cs));
+    HIPCHK(hipStreamWaitEvent(c->stream, s.copied, 0));
+    ppqc_batch d = *b;
+    d.bases = s.bases; d.quals = s.quals; d.offsets = s.offsets; d.channel = s.channel; d.mux = s.mux;
+    d.start_time_s = s.time; d.fail_flag = b->fail_flag ? s.ff : nullptr;
+    CHK(run_batch(c, &d));
+    HIPCHK(hipEventRecord(s.done, c->stream));
+    HIPCHK(hipEventRecord(c->ev_s1, c->stream));
+    s.busy = true;
+    return PPQC_OK;
+}
+
+static int resolve_timings(ppqc_ctx* c) {
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
+        c->timing.tile_kernel_ms_total += ms;
+        c->timing.tile_kernel_launches += 1;
+        c->timing.tile_kernel_bytes += p.bytes;
+        c->ev_pool.push_back(p.a);
+        c->ev_pool.push_back(p.b);
+    }
+    c->pending.clear();
+    return PPQC_OK;
+}
+
+int ppqc_sync(ppqc_ctx* c) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2; ++i) c->slot[i].busy = false;
+    return resolve_timings(c);
+}
+
+int ppqc_n_reads(ppqc_ctx* c, uint64_t* n) {
+    if (!c || !n) return fail(PPQC_E_INVALID, "null argument");
+    *n = c->n_reads;
+    return PPQC_OK;
+}
+
+int ppqc_read_stats(ppqc_ctx* c, const ppqc_per_read* o, uint64_t first, uint64_t n) {
+    if (!c || !o) return fail(PPQC_E_INVALID, "null argument");
+    if (first + n > c->n_reads) return fail(PPQC_E_INVALID, "read range out of bounds");
+    CHK(ppqc_sync(c));
+    if (n == 0) return PPQC_OK;
+    const ReadArrays& r = c->ra;
+#define D2H(dst, src, T) \
+    if (dst) HIPCHK(hipMemcpy(dst, (src) + first, n * sizeof(T), hipMemcpyDeviceToHost))
+    D2H(o->length, r.len, uint32_t); D2H(o->gc_count, r.gc, uint32_t); D2H(o->n_count, r.nn, uint32_t);
+    D2H(o->qsum, r.qsum, int64_t); D2H(o->mean_q, r.mean_q, double); D2H(o->err_hi, r.err_hi, uint64_t);
+    D2H(o->err_lo, r.err_lo, uint64_t); D2H(o->flags, r.flags, uint8_t);
+#undef D2H
+    return PPQC_OK;
+}
+
+int ppqc_read_hours(ppqc_ctx* c, int32_t* out, uint64_t first, uint64_t n) {
+    if (!c || !out) return fail(PPQC_E_INVALID, "null argument");
+    if (c->state < 2) return fail(PPQC_E_STATE, "hours are available after ppqc_finalize_tables");
+    if (first + n > c->n_reads) return fail(PPQC_E_INVALID, "read range out of bounds");
+    CHK(ppqc_sync(c));
+    if (n) HIPCHK(hipMemcpy(out, c->ra.hour + first, n * 4, hipMemcpyDeviceToHost));
+    return PPQC_OK;
+}
+
+int ppqc_finalize_extremes(ppqc_ctx* c) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint64_t nch1 = 1 + (uint64_t)c->cfg.n_channels;
+    HIPCHK(hipEventRecord(c->ev_t0, s));
+    HIPCHK(hipMemsetAsync(c->max_buf, 0, nch1 * 8, s));
+    HIPCHK(launch_fill_u64(c->min_buf, nch1, (uint64_t)INT64_MAX, s));
+    const int64_t init[2] = {INT64_MAX, INT64_MIN};
+    HIPCHK(hipMemcpyAsync(c->tminmax, init, 16, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // init[] is on the host stack
+    HIPCHK(launch_extremes(c->ra, c->n_reads, c->tp, c->max_buf, c->min_buf, c->tminmax, s));
+    c->state = 1;
+    return PPQC_OK;
+}
+
+static uint32_t bytes_mask_for(uint64_t maxval) {
+    uint32_t m = 0;
+    for (int b = 0; b < 8; ++b)
+        if ((maxval >> (8 * b)) & 0xFF || (maxval >> (8 * b)) > 0xFF) m |= 1u << b;
+    return m ? m : 1u;
+}
+
+int ppqc_finalize_tables(ppqc_ctx* c) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    if (c->state < 1) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes first");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint64_t n = c->n_reads;
+    HIPCHK(hipMemsetAsync(c->sum_buf, 0, c->tp.lay.n_sum * 8, s));
+    if (c->cfg.time_mode == 1 && n) {
+        int64_t tmm[2];
+        HIPCHK(hipMemcpyAsync(tmm, c->tminmax, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        uint64_t span = 0;
+        if (tmm[0] <= tmm[1]) {
+            span = (uint64_t)tmm[1] - (uint64_t)tmm[0];
+            if (span >= (1ull << 32)) return fail(PPQC_E_RANGE, "time_mode 1: start times span more than 2^32 s");
+        }
+        CHK(ensure_sort64(c, n));
+        HIPCHK(launch_mode1_keys(c->ra, n, c->tp, c->tminmax, c->sk64, c->vals, s));
+        const uint32_t mask = (bytes_mask_for(span) & 0xFu) | ((bytes_mask_for((uint64_t)c->cfg.n_channels + 1) & 0xFu) << 4);
+        HIPCHK(sort_u64_pairs(c->sk64, c->sk64_tmp, c->vals, c->vals_tmp, n, c->counts, mask, s));
+        HIPCHK(launch_mode1_hours(c->ra, n, c->tp, c->sk64, c->vals, c->chan_start, c->first_desc, s));
+    }
+    HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, c->max_buf, s));
+    c->state = 2;
+    return PPQC_OK;
+}
+
+int ppqc_finalize_n50(ppqc_ctx* c, const uint32_t* dlens, uint64_t n) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    if (c->state < 1) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes first");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (!dlens) { dlens = c->ra.lens32; n = c->n_reads; }
+    if (n >= (1ull << 32)) return fail(PPQC_E_RANGE, "more than 2^32-1 lengths");
+    HIPCHK(hipEventRecord(c->ev_s0, s));
+    uint64_t maxlen = 0;
+    HIPCHK(hipMemcpyAsync(&maxlen, c->max_buf, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    CHK(ensure_sort32(c, n ? n : 1));
+    if (n) HIPCHK(hipMemcpyAsync(c->sk32, dlens, n * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(sort_u32(c->sk32, c->sk32_tmp, n, c->counts, bytes_mask_for(maxlen), s));
+    HIPCHK(launch_n50(c->sk32, n, c->n50_blocks, c->n50_out, s));
+    HIPCHK(hipEventRecord(c->ev_s1, s));
+    HIPCHK(hipEventRecord(c->ev_t1, s));
+    c->state = 3;
+    return PPQC_OK;
+}
+
+int ppqc_fetch_tables(ppqc_ctx* c, ppqc_tables* o) {
+    if (!c || !o) return fail(PPQC_E_INVALID, "null argument");
+    if (c->state < 3) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes/tables/n50 first");
+    CHK(ppqc_sync(c));
+    const TableLayout& l = c->tp.lay;
+    std::vector<uint64_t> h(l.n_sum);
+    HIPCHK(hipMemcpy(h.data(), c->sum_buf, l.n_sum * 8, hipMemcpyDeviceToHost));
+    const uint64_t nch = l.n_channels, nb = l.n_time_bins, cells = nch * l.n_mux * nb;
+#define OUT(dst, off, cnt) if (dst) memcpy(dst, h.data() + (off), (cnt) * 8)
+    OUT(o->totals, l.off_totals, PPQC_N_TOTALS); OUT(o->len_hist_log2, l.off_len_log2, PPQC_N_LEN_LOG2);
+    OUT(o->len_hist_lin, l.off_len_lin, PPQC_N_LEN_LIN); OUT(o->q_hist, l.off_q_hist, PPQC_N_QHIST);
+    OUT(o->gc_hist, l.off_gc_hist, PPQC_N_GCHIST); OUT(o->hour_reads, l.off_hour_reads, nb);
+    OUT(o->hour_bases, l.off_hour_bases, nb); OUT(o->chan_reads, l.off_chan_reads, nch);
+    OUT(o->chan_bases, l.off_chan_bases, nch); OUT(o->chan_fail, l.off_chan_fail, nch);
+    OUT(o->cmh_reads, l.off_cmh_reads, cells); OUT(o->cmh_bases, l.off_cmh_bases, cells);
+#undef OUT
+    std::vector<uint64_t> mx(1 + nch), mn(1 + nch);
+    HIPCHK(hipMemcpy(mx.data(), c->max_buf, (1 + nch) * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(mn.data(), c->min_buf, (1 + nch) * 8, hipMemcpyDeviceToHost));
+    if (o->chan_max_len) memcpy(o->chan_max_len, mx.data() + 1, nch * 8);
+    if (o->chan_min_len) memcpy(o->chan_min_len, mn.data() + 1, nch * 8);
+    o->max_len = mx[0];
+    o->min_pos_len = mn[0];
+    o->lin_bin_width = mx[0] / PPQC_N_LEN_LIN + 1;
+    uint64_t n50[2];
+    HIPCHK(hipMemcpy(n50, c->n50_out, 16, hipMemcpyDeviceToHost));
+    o->n50 = c->n50 = n50[0];
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1) == hipSuccess) c->timing.finalize_ms_last = ms;
+    if (hipEventElapsedTime(&ms, c->ev_s0, c->ev_s1) == hipSuccess) c->timing.sort_ms_last = ms;
+    (void)hipGetLastError();   // an unrecorded event is not an error of the caller
+    return PPQC_OK;
+}
+
+int ppqc_finalize(ppqc_ctx* c, ppqc_tables* o) {
+    CHK(ppqc_finalize_extremes(c));
+    CHK(ppqc_finalize_tables(c));
+    CHK(ppqc_finalize_n50(c, nullptr, 0));
+    return ppqc_fetch_tables(c, o);
+}
+
+int ppqc_device_tables_view(ppqc_ctx* c, ppqc_device_tables* o) {
+    if (!c || !o) return fail(PPQC_E_INVALID, "null argument");
+    const TableLayout& l = c->tp.lay;
+    o->sum_buf = c->sum_buf; o->n_sum = l.n_sum;
+    o->max_buf = c->max_buf; o->n_max = 1 + (uint64_t)l.n_channels;
+    o->min_buf = c->min_buf; o->n_min = 1 + (uint64_t)l.n_channels;
+    o->lengths = c->ra.lens32; o->n_lengths = c->n_reads;
+    o->off_totals = l.off_totals; o->off_len_log2 = l.off_len_log2; o->off_len_lin = l.off_len_lin;
+    o->off_q_hist = l.off_q_hist; o->off_gc_hist = l.off_gc_hist; o->off_hour_reads = l.off_hour_reads;
+    o->off_hour_bases = l.off_hour_bases; o->off_chan_reads = l.off_chan_reads; o->off_chan_bases = l.off_chan_bases;
+    o->off_chan_fail = l.off_chan_fail; o->off_cmh_reads = l.off_cmh_reads; o->off_cmh_bases = l.off_cmh_bases;
+    return PPQC_OK;
+}
+
+int ppqc_timings(ppqc_ctx* c, ppqc_timing* o) {
+    if (!c || !o) return fail(PPQC_E_INVALID, "null argument");
+    CHK(ppqc_sync(c));
+    float ms = 0.f;
+    if (c->state == 0 && hipEventElapsedTime(&ms, c->ev_s0, c->ev_s1) == hipSuccess) c->timing.submit_ms_last = ms;
+    (void)hipGetLastError();
+    *o = c->timing;
+    return PPQC_OK;
+}
+
+int ppqc_reset_timings(ppqc_ctx* c) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    CHK(ppqc_sync(c));
+    c->timing = ppqc_timing{};
+    return PPQC_OK;
+}
+
+int ppqc_sort_u32_device(ppqc_ctx* c, uint32_t* keys, uint64_t n) {
+    if (!c || (!keys && n)) return fail(PPQC_E_INVALID, "null argument");
+    if (n >= (1ull << 32)) return fail(PPQC_E_RANGE, "more than 2^32-1 keys");
+    HIPCHK(hipSetDevice(c->device));
+    CHK(ensure_sort32(c, n ? n : 1));
+    HIPCHK(sort_u32(keys, c->sk32_tmp, n, c->counts, 0xFu, c->stream));
+    return PPQC_OK;
+}
+
+int ppqc_synth_fill_device(ppqc_ctx* c, uint8_t* bases, uint8_t* quals, uint64_t first, uint64_t n, uint64_t seed) {
+    if (!c || ((!bases || !quals) && n)) return fail(PPQC_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(launch_synth(bases, quals, first, n, seed, c->stream));
+    return PPQC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+// Internal declarations shared by the HIP translation units of libpypore_qc.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pypore_qc.h"
+
+namespace ppqc {
+
+constexpr int kWave = 64;               // CDNA wavefront
+constexpr int kVec = 16;                // bytes per lane per global_load_dwordx4
+constexpr int kSpan = kWave * kVec;     // 1 KiB: one wave-wide load of one stream
+constexpr int kTileSpans = 64;          // spans per tile
+constexpr uint64_t kTile = (uint64_t)kSpan * kTileSpans;   // 64 KiB of each stream per tile
+
+// A partial (or complete) per-read sum produced by one wave for one tile.
+//   cnt : packed counters  [0,26) sum of quality bytes, [26,44) N count, [44,62) G/C/S count
+//   hi  : sum over lanes of (lane error sum >> 32)
+//   lo  : sum over lanes of (lane error sum & 0xffffffff)      S = hi * 2^32 + lo
+struct __attribute__((aligned(32))) Partial {
+    uint64_t cnt, hi, lo, pad;
+};
+constexpr int kQbBits = 26, kNBits = 18;
+__host__ __device__ inline uint64_t pack_cnt(uint32_t gcs, uint32_t n, uint32_t qb) {
+    return (uint64_t)qb | ((uint64_t)n << kQbBits) | ((uint64_t)gcs << (kQbBits + kNBits));
+}
+__host__ __device__ inline uint32_t cnt_qb(uint64_t c) { return (uint32_t)(c & ((1ull << kQbBits) - 1)); }
+__host__ __device__ inline uint32_t cnt_n(uint64_t c) { return (uint32_t)((c >> kQbBits) & ((1ull << kNBits) - 1)); }
+__host__ __device__ inline uint32_t cnt_gcs(uint64_t c) { return (uint32_t)(c >> (kQbBits + kNBits)); }
+
+// Everything the per-read kernels need about one submitted batch (device pointers).
+struct BatchView {
+    const uint8_t* bases;
+    const uint8_t* quals;
+    const uint64_t* offsets;   // n_reads + 1, offsets[0] == 0
+    uint64_t n_reads, n_bytes;
+    const uint8_t* fail_flag;  // may be null
+};
+
+// Per-read record arrays of the context (device, capacity >= n_reads of the whole run).
+struct ReadArrays {
+    uint64_t *rec_cnt, *rec_hi, *rec_lo;   // raw sums written by the tile kernel / merged by finalize_reads
+    uint32_t *len, *gc, *nn;
+    int64_t* qsum;
+    double* mean_q;
+    uint64_t *err_hi, *err_lo;
+    uint8_t* flags;
+    uint32_t* channel;
+    uint8_t* mux;
+    int64_t* time;
+    int32_t* hour;
+    uint32_t* lens32;
+};
+
+struct TableLayout {
+    uint32_t n_channels, n_mux, n_time_bins;
+    uint64_t off_totals, off_len_log2, off_len_lin, off_q_hist, off_gc_hist, off_hour_reads, off_hour_bases,
+        off_chan_reads, off_chan_bases, off_chan_fail, off_cmh_reads, off_cmh_bases, n_sum;
+};
+
+struct TableParams {
+    TableLayout lay;
+    uint32_t bin_seconds, time_mode;
+    int32_t tz_offset_s;
+    int64_t ref_time_s;
+    uint64_t thr_fail;         // fixed-point image of fail_q
+    uint64_t thr_q[PPQC_N_QHIST + 1];   // images of 6,7,...,14
+    double fail_q;
+};
+
+// ---- launchers (each enqueues on `s`, returns the hipError of the launch) -----------------------------------------
+hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
+                              Partial* head, Partial* tail, int n_cu, hipStream_t s);
+hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
+                                 const Partial* tail, uint64_t thr_fail, double fail_q, hipStream_t s);
+
+hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* max_buf, uint64_t* min_buf,
+                           int64_t* tminmax, hipStream_t s);
+hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
+                         hipStream_t s);
+
+hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s);
+
+// time_mode 1 helpers
+hipError_t launch_mode1_keys(ReadArrays ra, uint64_t n, const TableParams& tp, const int64_t* tminmax, uint64_t* keys,
+                             uint32_t* vals, hipStream_t s);
+hipError_t launch_mode1_hours(ReadArrays ra, uint64_t n, const TableParams& tp, const uint64_t* sorted_keys,
+                              const uint32_t* sorted_vals, uint32_t* chan_start, uint32_t* first_desc,
+                              hipStream_t s);
+
+// Hand-written LSD radix sort.  `tmp_*` are ping-pong buffers of n elements, `counts` has 256*(n_waves+1)+256 u32.
+// On return the sorted data is in keys (and vals).  byte_mask selects which key bytes are sorted on.
+uint64_t sort_count_words(uint64_t n);
+hipError_t sort_u32(uint32_t* keys, uint32_t* tmp_keys, uint64_t n, uint32_t* counts, uint32_t byte_mask,
+                    hipStream_t s);
+hipError_t sort_u64_pairs(uint64_t* keys, uint64_t* tmp_keys, uint32_t* vals, uint32_t* tmp_vals, uint64_t n,
+                          uint32_t* counts, uint32_t byte_mask, hipStream_t s);
+
+// N50 over ascending-sorted lengths: out[0] = n50, out[1] = total bases.  block_sums has n/2048 + 2 u64.
+uint64_t n50_block_words(uint64_t n);
+hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s);
+
+hipError_t launch_synth(uint8_t* bases, uint8_t* quals, uint64_t first, uint64_t n, uint64_t seed, hipStream_t s);
+
+// ---- device helpers ----------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_add_u64(uint64_t v) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
+    return v + (((uint64_t)hi << 32) | lo);
+}
+// Sum over the 64 lanes of a fully active wave; the result is wave-uniform.
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+    v = dpp_add_u64<0x121>(v);   // row_ror:1
+    v = dpp_add_u64<0x122>(v);   // row_ror:2
+    v = dpp_add_u64<0x124>(v);   // row_ror:4
+    v = dpp_add_u64<0x128>(v);   // row_ror:8  -> every lane holds the sum of its 16-lane row
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    uint64_t t = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lo, r * 16);
+        uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)hi, r * 16);
+        t += ((uint64_t)h << 32) | l;
+    }
+    return t;
+}
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+#endif
+
+}  // namespace ppqc

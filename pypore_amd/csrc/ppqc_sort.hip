@@ -1,0 +1,246 @@
+// Hand-written LSD radix sort (8-bit digits, stable) and the exact N50 reduction over the sorted lengths (gfx950).
+//
+// The reference has no N50 (SURVEY.md 8a-11 vi defines it: sort lengths descending, first length whose running sum c
+// has 2c >= total); the sort also orders reads by (channel, start time) for the hour-wrap quirk of
+// lib/fast5_reader.py:117-126.  One wavefront owns one contiguous chunk of keys in all three phases of a pass, so
+// stability needs no cross-wave ordering inside a chunk:
+//   hist    : per-wave 256-bin digit histogram in LDS            -> counts[digit][wave]
+//   scan    : one block per digit scans its row, then the scatter waves prefix the 256 digit totals themselves
+//   scatter : per 64 keys, ballot-based match-any gives each lane its rank among equal digits (wave64: 64-bit masks)
+#include "ppqc_internal.hpp"
+
+namespace ppqc {
+
+constexpr uint32_t kMaxSortWaves = 2048;
+
+static inline void sort_geometry(uint64_t n, uint32_t* nw, uint32_t* chunk) {
+    uint64_t c = (n + kMaxSortWaves - 1) / kMaxSortWaves;
+    if (c < 2048) c = 2048;
+    c = (c + 63) & ~63ull;
+    *chunk = (uint32_t)c;
+    *nw = (uint32_t)((n + c - 1) / c);
+}
+
+uint64_t sort_count_words(uint64_t n) {
+    uint32_t nw, chunk;
+    sort_geometry(n ? n : 1, &nw, &chunk);
+    return 256ull * nw + 256;
+}
+
+template <typename K>
+__global__ __launch_bounds__(256) void rs_hist_kernel(const K* __restrict__ keys, uint64_t n, int shift,
+                                                      uint32_t* __restrict__ counts, uint32_t NW, uint32_t chunk) {
+    __shared__ uint32_t h[4][256];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t w = blockIdx.x * 4 + wib;
+    for (int d = lane; d < 256; d += 64) h[wib][d] = 0;
+    __syncthreads();
+    if (w < NW) {
+        const uint64_t base = (uint64_t)w * chunk;
+        const uint64_t end = base + chunk < n ? base + chunk : n;
+        for (uint64_t i = base + lane; i < end; i += 64) atomicAdd(&h[wib][(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (w < NW)
+        for (int d = lane; d < 256; d += 64) counts[(uint64_t)d * NW + w] = h[wib][d];
+}
+
+// Block d: exclusive scan of row d (NW entries) in place; row total -> counts[256*NW + d].
+__global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ counts, uint32_t NW) {
+    __shared__ uint32_t part[256];
+    const uint32_t d = blockIdx.x, t = threadIdx.x;
+    uint32_t* row = counts + (uint64_t)d * NW;
+    const uint32_t seg = (NW + 255) / 256;
+    const uint32_t b = t * seg, e = b + seg < NW ? b + seg : NW;
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; ++i) s += row[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; }
+        counts[256ull * NW + d] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[t];
+    for (uint32_t i = b; i < e; ++i) { const uint32_t v = row[i]; row[i] = run; run += v; }
+}
+
+template <typename K, bool HAS_VAL>
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const K* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                         K* __restrict__ okeys, uint32_t* __restrict__ ovals,
+                                                         uint64_t n, int shift, const uint32_t* __restrict__ counts,
+                                                         uint32_t NW, uint32_t chunk) {
+    __shared__ uint32_t base[4][256];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t w = blockIdx.x * 4 + wib;
+    if (w >= NW) return;   // whole waves leave; no block-level barrier below
+    // exclusive prefix of the 256 digit totals: lane owns digits 4*lane .. 4*lane+3
+    const uint32_t* tot = counts + 256ull * NW;
+    uint32_t t4[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { t4[j] = tot[lane * 4 + j]; s += t4[j]; }
+    uint32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    uint32_t run = inc - s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int d = lane * 4 + j;
+        base[wib][d] = run + counts[(uint64_t)d * NW + w];
+        run += t4[j];
+    }
+    const uint64_t b0 = (uint64_t)w * chunk;
+    const uint64_t end = b0 + chunk < n ? b0 + chunk : n;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (uint64_t r0 = b0; r0 < end; r0 += 64) {
+        const uint64_t i = r0 + lane;
+        const bool valid = i < end;
+        const K key = valid ? keys[i] : (K)0;
+        const uint32_t d = (uint32_t)(key >> shift) & 255u;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool one = (d >> bit) & 1u;
+            const uint64_t bm = __ballot(valid && one);
+            peers &= one ? bm : ~bm;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lt);
+        if (valid) {
+            const uint32_t pos = base[wib][d] + rank;
+            okeys[pos] = key;
+            if (HAS_VAL) ovals[pos] = vals[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) base[wib][d] += (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename K, bool HAS_VAL>
+static hipError_t radix_sort(K* keys, K* tmp_keys, uint32_t* vals, uint32_t* tmp_vals, uint64_t n, uint32_t* counts,
+                             uint32_t byte_mask, hipStream_t s) {
+    if (n < 2) return hipSuccess;
+    if (n >= (1ull << 32)) return hipErrorInvalidValue;
+    uint32_t NW, chunk;
+    sort_geometry(n, &NW, &chunk);
+    const unsigned blocks = (NW + 3) / 4;
+    K* src = keys; K* dst = tmp_keys;
+    uint32_t* vsrc = vals; uint32_t* vdst = tmp_vals;
+    for (int byte = 0; byte < (int)sizeof(K); ++byte) {
+        if (!((byte_mask >> byte) & 1u)) continue;
+        const int shift = 8 * byte;
+        hipLaunchKernelGGL((rs_hist_kernel<K>), dim3(blocks), dim3(256), 0, s, src, n, shift, counts, NW, chunk);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, s, counts, NW);
+        hipLaunchKernelGGL((rs_scatter_kernel<K, HAS_VAL>), dim3(blocks), dim3(256), 0, s, src, vsrc, dst, vdst, n,
+                           shift, counts, NW, chunk);
+        K* tk = src; src = dst; dst = tk;
+        uint32_t* tv = vsrc; vsrc = vdst; vdst = tv;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (src != keys) {
+        e = hipMemcpyAsync(keys, src, n * sizeof(K), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return e;
+        if (HAS_VAL) e = hipMemcpyAsync(vals, vsrc, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+    }
+    return e;
+}
+
+hipError_t sort_u32(uint32_t* keys, uint32_t* tmp_keys, uint64_t n, uint32_t* counts, uint32_t byte_mask,
+                    hipStream_t s) {
+    return radix_sort<uint32_t, false>(keys, tmp_keys, nullptr, nullptr, n, counts, byte_mask & 0xFu, s);
+}
+hipError_t sort_u64_pairs(uint64_t* keys, uint64_t* tmp_keys, uint32_t* vals, uint32_t* tmp_vals, uint64_t n,
+                          uint32_t* counts, uint32_t byte_mask, hipStream_t s) {
+    return radix_sort<uint64_t, true>(keys, tmp_keys, vals, tmp_vals, n, counts, byte_mask & 0xFFu, s);
+}
+
+// ---- N50 over ascending-sorted lengths -----------------------------------------------------------------------------
+// suffix(i) = sum_{j >= i} s[j];  N50 = s[i*] for the largest i* with 2 * suffix(i*) >= total.
+constexpr int kN50Items = 8;
+constexpr int kN50Block = 256 * kN50Items;
+
+uint64_t n50_block_words(uint64_t n) { return (n + kN50Block - 1) / kN50Block + 2; }
+
+__global__ __launch_bounds__(256) void n50_blocksum_kernel(const uint32_t* __restrict__ s, uint64_t n,
+                                                           uint64_t* __restrict__ bsum) {
+    __shared__ unsigned long long acc;
+    if (threadIdx.x == 0) acc = 0;
+    __syncthreads();
+    const uint64_t b0 = (uint64_t)blockIdx.x * kN50Block;
+    uint64_t t = 0;
+    for (int k = 0; k < kN50Items; ++k) {
+        const uint64_t i = b0 + (uint64_t)k * 256 + threadIdx.x;
+        if (i < n) t += s[i];
+    }
+    t = wave_sum_u64(t);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&acc, (unsigned long long)t);
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = acc;
+}
+
+// Single block: bsum[b] <- sum of the blocks after b (exclusive suffix); out[1] = total.
+__global__ __launch_bounds__(256) void n50_scan_kernel(uint64_t* __restrict__ bsum, uint64_t nblocks,
+                                                       uint64_t* __restrict__ out) {
+    __shared__ uint64_t part[256];
+    const uint32_t t = threadIdx.x;
+    const uint64_t seg = (nblocks + 255) / 256;
+    const uint64_t b = t * seg, e = b + seg < nblocks ? b + seg : nblocks;
+    uint64_t s = 0;
+    for (uint64_t i = b; i < e; ++i) s += bsum[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t run = 0;
+        for (int i = 255; i >= 0; --i) { const uint64_t v = part[i]; part[i] = run; run += v; }
+        out[1] = run;
+        out[0] = 0;
+    }
+    __syncthreads();
+    uint64_t run = part[t];
+    for (uint64_t i = e; i > b; --i) { const uint64_t v = bsum[i - 1]; bsum[i - 1] = run; run += v; }
+}
+
+__global__ __launch_bounds__(256) void n50_find_kernel(const uint32_t* __restrict__ s, uint64_t n,
+                                                       const uint64_t* __restrict__ bsuf, uint64_t* __restrict__ out) {
+    __shared__ uint64_t part[256];
+    const uint64_t total = out[1];
+    if (total == 0) return;
+    const uint32_t t = threadIdx.x;
+    const uint64_t b0 = (uint64_t)blockIdx.x * kN50Block + (uint64_t)t * kN50Items;   // thread owns 8 consecutive keys
+    uint32_t v[kN50Items];
+    uint64_t loc = 0;
+#pragma unroll
+    for (int k = 0; k < kN50Items; ++k) { const uint64_t i = b0 + k; v[k] = i < n ? s[i] : 0; loc += v[k]; }
+    part[t] = loc;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t run = bsuf[blockIdx.x];
+        for (int i = 255; i >= 0; --i) { const uint64_t x = part[i]; part[i] = run; run += x; }
+    }
+    __syncthreads();
+    uint64_t after = part[t];   // sum of everything after this thread's keys
+#pragma unroll
+    for (int k = kN50Items - 1; k >= 0; --k) {
+        const uint64_t i = b0 + k;
+        const uint64_t suf = after + v[k];
+        // predicate true at i, false at i+1 (or i is the last key)
+        if (i < n && 2 * suf >= total && (i + 1 == n || 2 * after < total)) out[0] = v[k];
+        after = suf;
+    }
+}
+
+hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
+    if (n == 0) return hipMemsetAsync(out, 0, 16, s);
+    const uint64_t nblocks = (n + kN50Block - 1) / kN50Block;
+    hipLaunchKernelGGL(n50_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sorted, n, block_sums);
+    hipLaunchKernelGGL(n50_scan_kernel, dim3(1), dim3(256), 0, s, block_sums, nblocks, out);
+    hipLaunchKernelGGL(n50_find_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sorted, n, block_sums, out);
+    return hipGetLastError();
+}
+
+}  // namespace ppqc

@@ -1,0 +1,274 @@
+// Run-level tables from the per-read records (gfx950): LDS-privatised histograms and per-channel accumulators flushed
+// with global atomics; per-(channel, mux, hour) cells by global atomics (too large for LDS at 3000 x 4 x 72).
+//
+// Replaces the aggregation of parsing_func (lib/fast5_reader.py:117-145 == lib/multi_read_fast5_reader.py:47-77), the
+// sums of FastStats (lib/seq_routines.py:99-137) and the per-channel tables of result_plotting / ChannelPlotter_f
+// (:378-394, :507-514, :673-680).  All cells are u64 so one RCCL dtype covers the merged buffer.
+#include "ppqc_internal.hpp"
+
+namespace ppqc {
+
+__device__ __forceinline__ int64_t floordiv64(int64_t a, int64_t b) {
+    int64_t q = a / b;
+    return ((a % b != 0) && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+// hour of day of (t - ref + tz): int(time.strftime('%H', time.localtime(t - ref)))  (lib/fast5_reader.py:118)
+__device__ __forceinline__ int32_t hour_of_day(int64_t t, const TableParams& tp) {
+    int64_t h = floordiv64(t - tp.ref_time_s + tp.tz_offset_s, 3600) % 24;
+    return (int32_t)(h < 0 ? h + 24 : h);
+}
+
+// ---- pass 1: extremes, sort input, absolute hour bins --------------------------------------------------------------
+__global__ __launch_bounds__(256) void extremes_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* max_buf,
+                                                       uint64_t* min_buf, int64_t* tminmax) {
+    __shared__ unsigned long long s_max, s_min;
+    __shared__ long long s_tmin, s_tmax;
+    if (threadIdx.x == 0) { s_max = 0; s_min = (unsigned long long)INT64_MAX; s_tmin = INT64_MAX; s_tmax = INT64_MIN; }
+    __syncthreads();
+    const uint32_t nch = tp.lay.n_channels;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t ch = ra.channel[i];
+        const bool good = ch >= 1 && ch <= nch;
+        const uint32_t L = ra.len[i];
+        ra.lens32[i] = good ? L : 0;
+        int32_t hour = -1;
+        if (good) {
+            atomicMax(&s_max, (unsigned long long)L);
+            if (L > 0) atomicMin(&s_min, (unsigned long long)L);
+            atomicMax((unsigned long long*)&max_buf[ch], (unsigned long long)L);
+            atomicMin((unsigned long long*)&min_buf[ch], (unsigned long long)L);
+            const int64_t t = ra.time[i];
+            atomicMin(&s_tmin, (long long)t);
+            atomicMax(&s_tmax, (long long)t);
+            if (tp.time_mode == 0) {
+                const int64_t h = floordiv64(t - tp.ref_time_s + tp.tz_offset_s, (int64_t)tp.bin_seconds);
+                hour = (h >= 0 && h < (int64_t)tp.lay.n_time_bins) ? (int32_t)h : -1;
+            }
+        }
+        if (tp.time_mode == 0) ra.hour[i] = hour;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax((unsigned long long*)&max_buf[0], s_max);
+        atomicMin((unsigned long long*)&min_buf[0], s_min);
+        atomicMin((long long*)&tminmax[0], s_tmin);
+        atomicMax((long long*)&tminmax[1], s_tmax);
+    }
+}
+
+// ---- pass 2: all SUM tables ------------------------------------------------------------------------------------------
+// Dynamic LDS layout (u64 first for alignment):
+//   u64 totals[16] | u64 hour_bases[nb] | u64 chan_bases[nchL] |
+//   u32 len_log2[40] | u32 len_lin[100] | u32 q[8] | u32 gc[20] | u32 hour_reads[nb] | u32 chan_reads[nchL] | u32 chan_fail[nchL]
+// nchL = n_channels when the per-channel accumulators fit in LDS, else 0 (then they go straight to global atomics).
+__global__ __launch_bounds__(256) void tables_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf,
+                                                     const uint64_t* max_buf, uint32_t nchL) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t nb = tp.lay.n_time_bins, nch = tp.lay.n_channels, nmux = tp.lay.n_mux;
+    unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(smem);
+    unsigned long long* s_hbases = s_tot + PPQC_N_TOTALS;
+    unsigned long long* s_cbases = s_hbases + nb;
+    uint32_t* s_log2 = reinterpret_cast<uint32_t*>(s_cbases + nchL);
+    uint32_t* s_lin = s_log2 + PPQC_N_LEN_LOG2;
+    uint32_t* s_q = s_lin + PPQC_N_LEN_LIN;
+    uint32_t* s_gc = s_q + PPQC_N_QHIST;
+    uint32_t* s_hreads = s_gc + PPQC_N_GCHIST;
+    uint32_t* s_creads = s_hreads + nb;
+    uint32_t* s_cfail = s_creads + nchL;
+    const uint32_t n64 = PPQC_N_TOTALS + nb + nchL;
+    const uint32_t n32 = PPQC_N_LEN_LOG2 + PPQC_N_LEN_LIN + PPQC_N_QHIST + PPQC_N_GCHIST + nb + 2 * nchL;
+    for (uint32_t k = threadIdx.x; k < n64; k += blockDim.x) s_tot[k] = 0;
+    for (uint32_t k = threadIdx.x; k < n32; k += blockDim.x) s_log2[k] = 0;
+    __syncthreads();
+
+    unsigned long long* g = reinterpret_cast<unsigned long long*>(sum_buf);
+    const uint64_t lin_w = max_buf[0] / PPQC_N_LEN_LIN + 1;
+    const bool chan_lds = nchL != 0;
+
+    uint64_t tot[PPQC_TOT_BAD_MUX + 1] = {};   // thread-local run totals, added to LDS once at the end
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        tot[PPQC_TOT_N_READS] += 1;
+        const uint32_t chn = ra.channel[i];
+        if (chn < 1 || chn > nch) { tot[PPQC_TOT_BAD_CHANNEL] += 1; continue; }
+        const uint32_t c = chn - 1;
+        const uint32_t L = ra.len[i];
+        const uint32_t gc = ra.gc[i];
+        const uint8_t fl = ra.flags[i];
+        const uint32_t fail = fl & 1u;
+        tot[PPQC_TOT_N_BASES] += L;
+        tot[PPQC_TOT_N_FAIL] += fail;
+        tot[PPQC_TOT_N_GC] += gc;
+        tot[PPQC_TOT_N_N] += ra.nn[i];
+        tot[PPQC_TOT_QSUM] += (uint64_t)ra.qsum[i];
+        tot[PPQC_TOT_ZERO_LEN] += (L == 0);
+        atomicAdd(&s_log2[L == 0 ? 0 : 32 - __clz(L)], 1u);
+        atomicAdd(&s_lin[L / lin_w], 1u);
+        // quality histogram: bin j <=> 6+j <= mean_q < 7+j <=> L*e(7+j) < S <= L*e(6+j)  (exact integers)
+        int qbin = -1;
+        if (fl & 2u) qbin = 0;   // flagged read: QScore 6.99
+        else if (L != 0) {
+            const unsigned __int128 S = ((unsigned __int128)ra.err_hi[i] << 32) + ra.err_lo[i];
+#pragma unroll
+            for (int j = 0; j < PPQC_N_QHIST; ++j)
+                if (qbin < 0 && S <= (unsigned __int128)L * tp.thr_q[j] && S > (unsigned __int128)L * tp.thr_q[j + 1]) qbin = j;
+        }
+        if (qbin >= 0) atomicAdd(&s_q[qbin], 1u);
+        if (gc > 0) {
+            uint32_t bin = (uint32_t)((20ull * gc) / L);
+            atomicAdd(&s_gc[bin > PPQC_N_GCHIST - 1 ? PPQC_N_GCHIST - 1 : bin], 1u);
+        }
+        if (chan_lds) { atomicAdd(&s_creads[c], 1u); atomicAdd(&s_cbases[c], (unsigned long long)L); }
+        else { atomicAdd(&g[tp.lay.off_chan_reads + c], 1ull); atomicAdd(&g[tp.lay.off_chan_bases + c], (unsigned long long)L); }
+        const uint32_t m = ra.mux[i];
+        if (m < 1 || m > nmux) { tot[PPQC_TOT_BAD_MUX] += 1; continue; }
+        if (fail) {
+            if (chan_lds) atomicAdd(&s_cfail[c], 1u);
+            else atomicAdd(&g[tp.lay.off_chan_fail + c], 1ull);
+        }
+        const int32_t h = ra.hour[i];
+        if (h < 0 || h >= (int32_t)nb) { tot[PPQC_TOT_TIME_OOB] += 1; continue; }
+        tot[PPQC_TOT_N_BINNED] += 1;
+        atomicAdd(&s_hreads[h], 1u);
+        atomicAdd(&s_hbases[h], (unsigned long long)L);
+        const uint64_t cell = ((uint64_t)c * nmux + (m - 1)) * nb + (uint32_t)h;
+        atomicAdd(&g[tp.lay.off_cmh_reads + cell], 1ull);
+        atomicAdd(&g[tp.lay.off_cmh_bases + cell], (unsigned long long)L);
+    }
+#pragma unroll
+    for (int k = 0; k <= PPQC_TOT_BAD_MUX; ++k)
+        if (tot[k]) atomicAdd(&s_tot[k], (unsigned long long)tot[k]);
+    __syncthreads();
+    // flush the non-zero privatised cells
+    for (uint32_t k = threadIdx.x; k < PPQC_N_TOTALS; k += blockDim.x)
+        if (s_tot[k]) atomicAdd(&g[tp.lay.off_totals + k], s_tot[k]);
+    for (uint32_t k = threadIdx.x; k < PPQC_N_LEN_LOG2; k += blockDim.x)
+        if (s_log2[k]) atomicAdd(&g[tp.lay.off_len_log2 + k], (unsigned long long)s_log2[k]);
+    for (uint32_t k = threadIdx.x; k < PPQC_N_LEN_LIN; k += blockDim.x)
+        if (s_lin[k]) atomicAdd(&g[tp.lay.off_len_lin + k], (unsigned long long)s_lin[k]);
+    for (uint32_t k = threadIdx.x; k < PPQC_N_QHIST; k += blockDim.x)
+        if (s_q[k]) atomicAdd(&g[tp.lay.off_q_hist + k], (unsigned long long)s_q[k]);
+    for (uint32_t k = threadIdx.x; k < PPQC_N_GCHIST; k += blockDim.x)
+        if (s_gc[k]) atomicAdd(&g[tp.lay.off_gc_hist + k], (unsigned long long)s_gc[k]);
+    for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) {
+        if (s_hreads[k]) atomicAdd(&g[tp.lay.off_hour_reads + k], (unsigned long long)s_hreads[k]);
+        if (s_hbases[k]) atomicAdd(&g[tp.lay.off_hour_bases + k], s_hbases[k]);
+    }
+    for (uint32_t k = threadIdx.x; k < nchL; k += blockDim.x) {
+        if (s_creads[k]) atomicAdd(&g[tp.lay.off_chan_reads + k], (unsigned long long)s_creads[k]);
+        if (s_cbases[k]) atomicAdd(&g[tp.lay.off_chan_bases + k], s_cbases[k]);
+        if (s_cfail[k]) atomicAdd(&g[tp.lay.off_chan_fail + k], (unsigned long long)s_cfail[k]);
+    }
+}
+
+// ---- time_mode 1: reference hour-of-day + wrap quirk (lib/fast5_reader.py:117-126) ---------------------------------
+// Sequential rule: for index e > 1 in start-time order, hour[e] += 24 if hour[e] < hour[e-1] (already fixed value).
+// Once a read is bumped (>= 24) every later read compares below it, so bumped(e) = OR_{2<=j<=e} (h[j] < h[j-1]) on the
+// raw hours: all reads from the first descent at index >= 2 onwards get +24.
+__global__ __launch_bounds__(256) void mode1_keys_kernel(ReadArrays ra, uint64_t n, TableParams tp,
+                                                         const int64_t* tminmax, uint64_t* keys, uint32_t* vals) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ch = ra.channel[i];
+    const bool good = ch >= 1 && ch <= tp.lay.n_channels;
+    // reads with a bad channel sort behind every real channel (sentinel channel n_channels + 1) and are skipped later
+    keys[i] = good ? (((uint64_t)ch << 32) | (uint64_t)(uint32_t)(ra.time[i] - tminmax[0]))
+                   : ((uint64_t)(tp.lay.n_channels + 1) << 32);
+    vals[i] = (uint32_t)i;
+    ra.hour[i] = -1;
+}
+
+__global__ __launch_bounds__(256) void mode1_starts_kernel(const uint64_t* keys, uint64_t n, uint32_t nch,
+                                                           uint32_t* chan_start) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t ch = (uint32_t)(keys[p] >> 32);
+    if (ch > nch) return;
+    if (p == 0 || (uint32_t)(keys[p - 1] >> 32) != ch) chan_start[ch - 1] = (uint32_t)p;
+}
+
+__global__ __launch_bounds__(256) void mode1_descent_kernel(ReadArrays ra, uint64_t n, TableParams tp,
+                                                            const uint64_t* keys, const uint32_t* vals,
+                                                            const uint32_t* chan_start, uint32_t* first_desc) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t ch = (uint32_t)(keys[p] >> 32);
+    if (ch > tp.lay.n_channels) return;
+    const uint32_t pos = (uint32_t)p - chan_start[ch - 1];
+    if (pos < 2) return;
+    const int32_t h = hour_of_day(ra.time[vals[p]], tp), hp = hour_of_day(ra.time[vals[p - 1]], tp);
+    if (h < hp) atomicMin(&first_desc[ch - 1], pos);
+}
+
+__global__ __launch_bounds__(256) void mode1_assign_kernel(ReadArrays ra, uint64_t n, TableParams tp,
+                                                           const uint64_t* keys, const uint32_t* vals,
+                                                           const uint32_t* chan_start, const uint32_t* first_desc) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t ch = (uint32_t)(keys[p] >> 32);
+    if (ch > tp.lay.n_channels) return;
+    const uint32_t pos = (uint32_t)p - chan_start[ch - 1];
+    const uint32_t idx = vals[p];
+    int32_t h = hour_of_day(ra.time[idx], tp) + (pos >= first_desc[ch - 1] ? 24 : 0);
+    ra.hour[idx] = h < (int32_t)tp.lay.n_time_bins ? h : -1;
+}
+
+__global__ void fill_u64_kernel(uint64_t* p, uint64_t n, uint64_t v) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+
+static inline unsigned grid_for(uint64_t n, unsigned cap) {
+    uint64_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* max_buf, uint64_t* min_buf,
+                           int64_t* tminmax, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(extremes_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, s, ra, n, tp, max_buf, min_buf, tminmax);
+    return hipGetLastError();
+}
+
+hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
+                         hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint32_t nb = tp.lay.n_time_bins;
+    // per-channel accumulators in LDS need 16 B per channel; keep the block under 64 KiB so 2 blocks fit a CU
+    const uint32_t nchL = tp.lay.n_channels <= 3584 ? tp.lay.n_channels : 0;
+    const size_t lds = 8ull * (PPQC_N_TOTALS + nb + nchL) +
+                       4ull * (PPQC_N_LEN_LOG2 + PPQC_N_LEN_LIN + PPQC_N_QHIST + PPQC_N_GCHIST + nb + 2ull * nchL);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    // few, fat blocks: every block flushes its private tables once
+    hipLaunchKernelGGL(tables_kernel, dim3(grid_for(n, 512)), dim3(256), lds, s, ra, n, tp, sum_buf, max_buf, nchL);
+    return hipGetLastError();
+}
+
+hipError_t launch_mode1_keys(ReadArrays ra, uint64_t n, const TableParams& tp, const int64_t* tminmax, uint64_t* keys,
+                             uint32_t* vals, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(mode1_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ra, n, tp, tminmax, keys,
+                       vals);
+    return hipGetLastError();
+}
+
+hipError_t launch_mode1_hours(ReadArrays ra, uint64_t n, const TableParams& tp, const uint64_t* keys,
+                              const uint32_t* vals, uint32_t* chan_start, uint32_t* first_desc, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipError_t e = hipMemsetAsync(first_desc, 0xFF, sizeof(uint32_t) * tp.lay.n_channels, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mode1_starts_kernel, dim3(blocks), dim3(256), 0, s, keys, n, tp.lay.n_channels, chan_start);
+    hipLaunchKernelGGL(mode1_descent_kernel, dim3(blocks), dim3(256), 0, s, ra, n, tp, keys, vals, chan_start,
+                       first_desc);
+    hipLaunchKernelGGL(mode1_assign_kernel, dim3(blocks), dim3(256), 0, s, ra, n, tp, keys, vals, chan_start,
+                       first_desc);
+    return hipGetLastError();
+}
+
+}  // namespace ppqc

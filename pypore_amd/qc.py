@@ -1,0 +1,214 @@
+"""Host driver of the GPU per-read QC path: one ``QCContext`` per GPU.
+
+This is the piece that replaces the pool of ``Consumer`` processes and the per-channel tasks of the
+reference (lib/seq_routines.py:916-942: ``Q.put(f5r.parsing_func(...))`` ... ``ChannelDict[...] =
+result[1:6]``): loaders hand over reads packed as CSR, the library computes the per-read records
+and the run-level tables on the GPU, and ``tables()`` returns what ``FastStats`` /
+``result_plotting`` consume.  All compute goes through the C ABI (include/pypore_qc.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceArrayView:
+    """Zero-copy view of device memory for ``torch.as_tensor(view, device='cuda')`` (RCCL all-reduce)."""
+
+    def __init__(self, ptr, n, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr or 0), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner
+
+
+class QCContext:
+    def __init__(self, device=0, n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=0,
+                 tz_offset_s=0, ref_time_s=0, fail_q=7.0, max_reads_hint=0):
+        self._lib = L.load()
+        cfg = L.Config()
+        L.check(self._lib.ppqc_config_default(C.byref(cfg)))
+        cfg.n_channels, cfg.n_mux, cfg.n_time_bins, cfg.bin_seconds = n_channels, n_mux, n_time_bins, bin_seconds
+        cfg.time_mode, cfg.tz_offset_s, cfg.ref_time_s, cfg.fail_q = time_mode, tz_offset_s, int(ref_time_s), fail_q
+        cfg.max_reads_hint = int(max_reads_hint)
+        self.cfg = cfg
+        self._ctx = C.c_void_p()
+        L.check(self._lib.ppqc_create(C.byref(self._ctx), int(device), C.byref(cfg)))
+        self._keep = []   # host arrays that must outlive an asynchronous submit
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.ppqc_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def reset(self):
+        L.check(self._lib.ppqc_reset(self._ctx))
+        self._keep.clear()
+
+    # -- submitting reads ---------------------------------------------------------------------------
+    def submit(self, bases, quals, offsets, channel, mux, start_time_s, fail_flag=None, slot=0):
+        """Host CSR batch (numpy arrays; see ``pack_reads``).  Asynchronous until ``sync``."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        channel = np.ascontiguousarray(channel, dtype=np.uint32)
+        mux = np.ascontiguousarray(mux, dtype=np.uint8)
+        t = np.ascontiguousarray(start_time_s, dtype=np.int64)
+        ff = None if fail_flag is None else np.ascontiguousarray(fail_flag, dtype=np.uint8)
+        R = len(offsets) - 1
+        if R < 0 or len(channel) != R or len(mux) != R or len(t) != R or (ff is not None and len(ff) != R):
+            raise ValueError("metadata arrays must have one entry per read")
+        nbytes = int(offsets[-1]) if R > 0 else 0
+        if len(bases) < nbytes or len(quals) < nbytes:
+            raise ValueError("bases/quals shorter than offsets[-1]")
+        b = L.Batch(R, nbytes, _ptr(bases), _ptr(quals), _ptr(offsets), _ptr(channel), _ptr(mux), _ptr(t), _ptr(ff))
+        self._keep.append((bases, quals, offsets, channel, mux, t, ff))
+        L.check(self._lib.ppqc_submit(self._ctx, C.byref(b), int(slot)))
+
+    def submit_device(self, n_reads, n_bytes, bases_ptr, quals_ptr, offsets_ptr, channel_ptr, mux_ptr, time_ptr,
+                      fail_flag_ptr=None):
+        """Batch already resident in HBM (raw device pointers, e.g. ``tensor.data_ptr()``)."""
+        b = L.Batch(int(n_reads), int(n_bytes), bases_ptr, quals_ptr, offsets_ptr, channel_ptr, mux_ptr, time_ptr,
+                    fail_flag_ptr)
+        L.check(self._lib.ppqc_submit_device(self._ctx, C.byref(b)))
+
+    def sync(self):
+        L.check(self._lib.ppqc_sync(self._ctx))
+        self._keep.clear()
+
+    @property
+    def n_reads(self):
+        n = C.c_uint64()
+        L.check(self._lib.ppqc_n_reads(self._ctx, C.byref(n)))
+        return n.value
+
+    # -- results ------------------------------------------------------------------------------------
+    def read_stats(self, first=0, n=None):
+        """Per-read records as a dict of numpy arrays; ``err`` is the exact fixed-point sum (Python ints)."""
+        if n is None:
+            n = self.n_reads - first
+        out = dict(length=np.zeros(n, np.uint32), gc=np.zeros(n, np.uint32), n=np.zeros(n, np.uint32),
+                   qsum=np.zeros(n, np.int64), mean_q=np.zeros(n, np.float64), err_hi=np.zeros(n, np.uint64),
+                   err_lo=np.zeros(n, np.uint64), flags=np.zeros(n, np.uint8))
+        pr = L.PerRead(_ptr(out["length"]), _ptr(out["gc"]), _ptr(out["n"]), _ptr(out["qsum"]), _ptr(out["mean_q"]),
+                       _ptr(out["err_hi"]), _ptr(out["err_lo"]), _ptr(out["flags"]))
+        L.check(self._lib.ppqc_read_stats(self._ctx, C.byref(pr), int(first), int(n)))
+        self._keep.clear()
+        return out
+
+    @staticmethod
+    def err_exact(stats):
+        return np.array([(int(h) << 32) + int(l) for h, l in zip(stats["err_hi"], stats["err_lo"])], dtype=object)
+
+    def read_hours(self, first=0, n=None):
+        if n is None:
+            n = self.n_reads - first
+        out = np.zeros(n, np.int32)
+        L.check(self._lib.ppqc_read_hours(self._ctx, _ptr(out), int(first), int(n)))
+        return out
+
+    def _alloc_tables(self):
+        nch, nmux, nb = self.cfg.n_channels, self.cfg.n_mux, self.cfg.n_time_bins
+        z = lambda *s: np.zeros(s, dtype=np.uint64)
+        arr = dict(totals=z(L.N_TOTALS), len_hist_log2=z(L.N_LEN_LOG2), len_hist_lin=z(L.N_LEN_LIN),
+                   q_hist=z(L.N_QHIST), gc_hist=z(L.N_GCHIST), hour_reads=z(nb), hour_bases=z(nb), chan_reads=z(nch),
+                   chan_bases=z(nch), chan_fail=z(nch), cmh_reads=z(nch, nmux, nb), cmh_bases=z(nch, nmux, nb),
+                   chan_min_len=z(nch), chan_max_len=z(nch))
+        t = L.Tables()
+        for k, a in arr.items():
+            setattr(t, k, a.ctypes.data)
+        return arr, t
+
+    @staticmethod
+    def _tables_dict(arr, t):
+        out = {k: a.astype(np.int64) for k, a in arr.items()}   # two's complement view (qsum may be negative)
+        out.update(max_len=int(t.max_len), min_pos_len=int(t.min_pos_len), lin_bin_width=int(t.lin_bin_width),
+                   n50=int(t.n50))
+        return out
+
+    def finalize(self):
+        """Single-GPU run-level tables (extremes -> tables -> radix sort + N50 -> fetch)."""
+        arr, t = self._alloc_tables()
+        L.check(self._lib.ppqc_finalize(self._ctx, C.byref(t)))
+        self._keep.clear()
+        return self._tables_dict(arr, t)
+
+    # phased finalize for multi-GPU merges
+    def finalize_extremes(self):
+        L.check(self._lib.ppqc_finalize_extremes(self._ctx))
+
+    def finalize_tables(self):
+        L.check(self._lib.ppqc_finalize_tables(self._ctx))
+
+    def finalize_n50(self, lengths_ptr=None, n=0):
+        L.check(self._lib.ppqc_finalize_n50(self._ctx, lengths_ptr, int(n)))
+
+    def fetch_tables(self):
+        arr, t = self._alloc_tables()
+        L.check(self._lib.ppqc_fetch_tables(self._ctx, C.byref(t)))
+        return self._tables_dict(arr, t)
+
+    def device_tables(self):
+        """Zero-copy device views {sum, max, min (int64), lengths (uint32)} plus the table offsets."""
+        d = L.DeviceTables()
+        L.check(self._lib.ppqc_device_tables_view(self._ctx, C.byref(d)))
+        views = dict(sum=DeviceArrayView(d.sum_buf, d.n_sum, "<i8", self),
+                     max=DeviceArrayView(d.max_buf, d.n_max, "<i8", self),
+                     min=DeviceArrayView(d.min_buf, d.n_min, "<i8", self),
+                     lengths=DeviceArrayView(d.lengths, d.n_lengths, "<i4", self))
+        return views, d
+
+    def timings(self):
+        t = L.Timing()
+        L.check(self._lib.ppqc_timings(self._ctx, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in L.Timing._fields_}
+
+    def reset_timings(self):
+        L.check(self._lib.ppqc_reset_timings(self._ctx))
+
+    # -- device utilities -----------------------------------------------------------------------------
+    def sort_u32_device(self, keys_ptr, n):
+        L.check(self._lib.ppqc_sort_u32_device(self._ctx, keys_ptr, int(n)))
+
+    def synth_fill_device(self, bases_ptr, quals_ptr, first, n, seed):
+        L.check(self._lib.ppqc_synth_fill_device(self._ctx, bases_ptr, quals_ptr, int(first), int(n), int(seed)))
+
+
+def device_count():
+    n = C.c_int()
+    L.check(L.load().ppqc_device_count(C.byref(n)))
+    return n.value
+
+
+def pack_reads(records):
+    """Pack an iterable of (bases: bytes, quals: bytes) into the CSR arrays ``submit`` takes
+    (the FASTQ record of lib/fastqparser.py:7-16: bases = line 2, quals = line 4)."""
+    bs, qs, offs = [], [], [0]
+    for b, q in records:
+        if len(b) != len(q):
+            raise ValueError("sequence/quality length mismatch")
+        bs.append(b)
+        qs.append(q)
+        offs.append(offs[-1] + len(b))
+    bases = np.frombuffer(b"".join(bs), dtype=np.uint8)
+    quals = np.frombuffer(b"".join(qs), dtype=np.uint8)
+    return bases, quals, np.asarray(offs, dtype=np.uint64)

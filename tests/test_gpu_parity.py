@@ -1,0 +1,222 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+Integers, histograms, tables and N50 must be bit-exact; mean quality within 1e-6 relative
+(north_star), and within 1e-12 of the fixed-point model it is computed from."""
+import numpy as np
+import pytest
+
+from util import random_batch, assert_tables_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qc():
+    from pypore_amd import qc as m
+    return m
+
+
+def _check_reads(got, want, flagged=None):
+    n = len(want["length"])
+    fl = np.zeros(n, bool) if flagged is None else np.asarray(flagged).astype(bool)
+    keep = ~fl
+    for k in ("length", "gc", "n", "qsum"):
+        g, w = got[k][keep], want[k][keep]
+        if not np.array_equal(g, w):
+            i = np.nonzero(g != w)[0][:5]
+            raise AssertionError("per-read %s differs at %s: got %s want %s (len %s)" % (
+                k, np.nonzero(keep)[0][i], g[i], w[i], want["length"][keep][i]))
+    for k in ("length", "gc", "n", "qsum", "err_hi", "err_lo"):
+        assert not got[k][fl].any(), k
+    assert np.all(got["mean_q"][fl] == 6.99)
+    gerr = [(int(h) << 32) + int(l) for h, l in zip(got["err_hi"], got["err_lo"])]
+    idx = np.nonzero(keep)[0]
+    bad = [i for i in idx if gerr[i] != int(want["err"][i])]
+    assert not bad, ("fixed-point error sums differ", bad[:5], [gerr[i] for i in bad[:5]],
+                     [int(want["err"][i]) for i in bad[:5]])
+    assert np.all(got["err_lo"] < (1 << 32))
+    np.testing.assert_allclose(got["mean_q"][keep], want["mean_q"][keep], rtol=1e-12, atol=1e-12)
+
+
+def _run(qc, b, cfg, c_oracle, use_ff=True, split=None):
+    ff = b["fail_flag"] if use_ff else None
+    with qc.QCContext(device=0, **cfg) as ctx:
+        if split is None:
+            ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], ff)
+        else:   # stream the same reads as several host batches through the two staging slots
+            R = len(b["channel"])
+            cuts = np.linspace(0, R, split + 1).astype(int)
+            for k in range(split):
+                a, e = cuts[k], cuts[k + 1]
+                o = b["offsets"][a:e + 1]
+                s0, s1 = int(o[0]), int(o[-1])
+                ctx.submit(b["bases"][s0:s1], b["quals"][s0:s1], o - o[0], b["channel"][a:e], b["mux"][a:e],
+                           b["time"][a:e], None if ff is None else ff[a:e], slot=k % 2)
+        ctx.sync()
+        got = ctx.read_stats()
+        tables = ctx.finalize()
+        hours = ctx.read_hours()
+    want = c_oracle.per_read(b["bases"], b["quals"], b["offsets"], nthreads=4)
+    _check_reads(got, want, ff)
+    wt = c_oracle.tables(want, b["channel"], b["mux"], b["time"], ff, cfg)
+    assert_tables_equal(tables, wt, str(cfg))
+    return got, tables, hours
+
+
+BASE_CFG = dict(n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=0, tz_offset_s=0,
+                ref_time_s=1_528_000_000, fail_q=7.0)
+
+
+@pytest.mark.parametrize("seed,n_reads,mean_len", [(1, 300, 300), (2, 4000, 900), (3, 20000, 3000), (4, 64, 40000)])
+def test_per_read_and_tables_mode0(qc, c_oracle, seed, n_reads, mean_len):
+    b = random_batch(seed, n_reads, mean_len)
+    _run(qc, b, BASE_CFG, c_oracle)
+
+
+@pytest.mark.parametrize("seed,n_reads,n_channels", [(11, 500, 12), (12, 6000, 512), (13, 3000, 3)])
+def test_tables_mode1_hour_wrap_quirk(qc, c_oracle, seed, n_reads, n_channels):
+    cfg = dict(BASE_CFG, time_mode=1, n_channels=n_channels, tz_offset_s=3600)
+    b = random_batch(seed, n_reads, 200, n_channels=n_channels, hours=47)
+    _run(qc, b, cfg, c_oracle)
+
+
+def test_promethion_shape_3000_channels_72_bins(qc, c_oracle):
+    cfg = dict(BASE_CFG, n_channels=3000, n_time_bins=72)
+    b = random_batch(21, 30000, 150, n_channels=3000, hours=75)   # some reads beyond the last bin
+    _, tables, _ = _run(qc, b, cfg, c_oracle)
+    assert tables["totals"][8] > 0   # time_oob exercised
+
+
+def test_streamed_batches_equal_single_batch(qc, c_oracle):
+    b = random_batch(31, 5000, 700)
+    g1, t1, h1 = _run(qc, b, BASE_CFG, c_oracle)
+    g2, t2, h2 = _run(qc, b, BASE_CFG, c_oracle, split=7)
+    for k in g1:
+        assert np.array_equal(g1[k], g2[k]), k
+    assert_tables_equal(t1, t2)
+    assert np.array_equal(h1, h2)
+
+
+def test_no_fail_flag_and_all_flagged(qc, c_oracle):
+    b = random_batch(41, 800, 500)
+    _run(qc, b, BASE_CFG, c_oracle, use_ff=False)
+    b["fail_flag"][:] = 1
+    _run(qc, b, BASE_CFG, c_oracle)
+
+
+def test_empty_and_degenerate_batches(qc, c_oracle):
+    z8, z64 = np.zeros(0, np.uint8), np.zeros(1, np.uint64)
+    with qc.QCContext(device=0, **BASE_CFG) as ctx:
+        ctx.submit(z8, z8, z64, np.zeros(0, np.uint32), z8, np.zeros(0, np.int64))
+        t = ctx.finalize()
+        assert t["totals"].sum() == 0 and t["n50"] == 0 and t["max_len"] == 0
+    # only empty reads
+    b = dict(bases=z8, quals=z8, offsets=np.zeros(6, np.uint64), channel=np.arange(1, 6, dtype=np.uint32),
+             mux=np.ones(5, np.uint8), time=np.full(5, 1_528_000_000, np.int64), fail_flag=np.zeros(5, np.uint8))
+    _run(qc, b, BASE_CFG, c_oracle)
+    # a single one-base read, a single read of exactly one tile, and one just over a tile
+    for L in (1, 65536, 65537):
+        rng = np.random.default_rng(L)
+        b = dict(bases=rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), L), quals=rng.integers(33, 80, L).astype(np.uint8),
+                 offsets=np.array([0, L], np.uint64), channel=np.array([7], np.uint32), mux=np.array([2], np.uint8),
+                 time=np.array([1_528_000_100], np.int64), fail_flag=np.zeros(1, np.uint8))
+        _run(qc, b, BASE_CFG, c_oracle)
+
+
+def test_known_answers(qc):
+    """Hand-derived KATs of SURVEY.md 8a-2 / 8a-11."""
+    recs = [(b"ACTGN", b"!+5?I"), (b"GGCCSsgcAT", b"IIIIIIIIII"), (b"", b""), (b"nNnN", b"!!!!")]
+    bases, quals, off = qc.pack_reads(recs)
+    with qc.QCContext(device=0, **BASE_CFG) as ctx:
+        ctx.submit(bases, quals, off, np.ones(4, np.uint32), np.ones(4, np.uint8), np.full(4, 1_528_000_000, np.int64))
+        s = ctx.read_stats()
+    assert s["length"].tolist() == [5, 10, 0, 4]
+    assert s["gc"].tolist() == [2, 8, 0, 0]          # GC("ACTGN") = 40.0, GC("GGCCSsgcAT") = 80.0
+    assert s["n"].tolist() == [1, 0, 0, 4]
+    assert s["qsum"].tolist() == [100, 400, 0, 0]
+    assert abs(s["mean_q"][0] - 6.5321685674187755) < 1e-6 * 6.53
+    assert abs(s["mean_q"][1] - 40.0) < 1e-6 * 40 and s["mean_q"][2] == 0.0 and abs(s["mean_q"][3]) < 1e-9
+    assert s["flags"].tolist() == [1, 0, 1, 1]       # 6.53 < 7 fail; 40 pass; empty read q=0 fail; q=0 fail
+
+
+def test_mean_q_matches_float_spec(qc):
+    """north_star: mean quality within 1e-6 relative of -10 log10(mean 10^(-q/10)) in plain fp64."""
+    from oracle import pypore_oracle as po
+    b = random_batch(51, 400, 800, invalid_quals=False)
+    with qc.QCContext(device=0, **BASE_CFG) as ctx:
+        ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"])
+        s = ctx.read_stats()
+    for i in range(len(b["channel"])):
+        a, e = int(b["offsets"][i]), int(b["offsets"][i + 1])
+        spec = po.mean_q_ont(b["quals"][a:e].tobytes())
+        assert abs(s["mean_q"][i] - spec) <= 1e-6 * max(abs(spec), 1e-30), (i, s["mean_q"][i], spec)
+
+
+def test_radix_sort_and_n50(qc, c_oracle):
+    import torch
+    rng = np.random.default_rng(7)
+    with qc.QCContext(device=0, **BASE_CFG) as ctx:
+        for n in (1, 2, 63, 64, 65, 2047, 2048, 2049, 100_000, 3_000_001):
+            keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+            if n > 1000:
+                keys[: n // 3] &= 0xFFFF     # many equal high digits
+                keys[n // 3: n // 2] = 12345  # long runs of equal keys
+            t = torch.from_numpy(keys.view(np.int32).copy()).cuda()
+            ctx.sort_u32_device(t.data_ptr(), n)
+            ctx.sync()
+            got = t.cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, np.sort(keys)), n
+    for lens in ([2, 2, 2, 3, 3, 4, 8, 8], [10, 20, 30, 40, 50], [5], [0, 0, 0], [7] * 5000,
+                 rng.integers(1, 2_000_000, 70_001).tolist()):
+        R = len(lens)
+        off = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+        nb = int(off[-1])
+        with qc.QCContext(device=0, **BASE_CFG) as ctx:
+            ctx.submit(np.full(nb, ord("A"), np.uint8), np.full(nb, 50, np.uint8), off, np.ones(R, np.uint32),
+                       np.ones(R, np.uint8), np.full(R, 1_528_000_000, np.int64))
+            t = ctx.finalize()
+        assert t["n50"] == c_oracle.n50(lens), (lens[:8], t["n50"])
+    assert c_oracle.n50([2, 2, 2, 3, 3, 4, 8, 8]) == 8 and c_oracle.n50([10, 20, 30, 40, 50]) == 40
+
+
+def test_synth_generator_matches_numpy(qc):
+    import torch
+    from pypore_amd import synth
+    with qc.QCContext(device=0, **BASE_CFG) as ctx:
+        for first, n in ((0, 4096), (5, 100_003), (1 << 33, 70_001), (3, 1)):
+            tb = torch.zeros(n + 32, dtype=torch.uint8, device="cuda")
+            tq = torch.zeros(n + 32, dtype=torch.uint8, device="cuda")
+            ctx.synth_fill_device(tb.data_ptr(), tq.data_ptr(), first, n, 20240601)
+            ctx.sync()
+            hb, hq = synth.stream_bytes(first, n, 20240601)
+            assert np.array_equal(tb.cpu().numpy()[:n], hb) and np.array_equal(tq.cpu().numpy()[:n], hq)
+            assert not tb.cpu().numpy()[n:].any()
+
+
+def test_device_batch_config4_adversarial_and_determinism(qc, c_oracle):
+    """Ultra-long reads split over many wavefronts + thousands of tiny reads, generated in HBM; checked against
+    the oracle on the regenerated host copy, and bit-identical across two runs."""
+    import torch
+    from pypore_amd import synth
+    seed = 99
+    lens = synth.adversarial_lengths(20_000, seed, n_long=6, long_len=2_000_000)
+    lens[:50] = synth.read_lengths(50, 10.1266, 1.1774, seed)
+    off = synth.offsets_from_lengths(lens)
+    nb, R = int(off[-1]), len(lens)
+    ch, mux, t = synth.metadata(R, 512, 48, seed)
+    outs = []
+    with qc.QCContext(device=0, **BASE_CFG) as ctx:
+        tb = torch.empty(nb + 64, dtype=torch.uint8, device="cuda")
+        tq = torch.empty(nb + 64, dtype=torch.uint8, device="cuda")
+        ctx.synth_fill_device(tb.data_ptr(), tq.data_ptr(), 0, nb, seed)
+        d = [torch.from_numpy(x).cuda() for x in (off.view(np.int64), ch.view(np.int32), mux, t)]
+        for _ in range(2):
+            ctx.reset()
+            ctx.submit_device(R, nb, tb.data_ptr(), tq.data_ptr(), *[x.data_ptr() for x in d])
+            outs.append((ctx.read_stats(), ctx.finalize()))
+    hb, hq = synth.stream_bytes(0, nb, seed)
+    want = c_oracle.per_read(hb, hq, off, nthreads=8)
+    _check_reads(outs[0][0], want)
+    assert_tables_equal(outs[0][1], c_oracle.tables(want, ch, mux, t, None, BASE_CFG))
+    for k in outs[0][0]:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+    assert_tables_equal(outs[0][1], outs[1][1])
