@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py -- Gbases/s of the per-read QC statistics path (BASELINE.json metric) on N MI355X of one node.
+
+A step = one whole pass of the hot path over one resident batch: reset, per-read segmented reduction over the CSR
+batch, per-read finalisation, extremes, run-level tables, radix sort + N50 and, for N > 1, the RCCL merges
+(all-reduce MAX/MIN of the extremes, all-reduce SUM of the fused table buffer, all-gather of the lengths).
+Inputs are synthetic (BASELINE.md config 2 shape: 1 M reads per GPU, log-normal lengths with N50 ~ 20 kb, about
+10 Gbases + 10 Gquals per GPU) and are generated in HBM before the timed region.  Weak scaling: every rank holds its
+own config-2 shard.
+
+Prints ONE JSON line on rank 0 (see the contract in DESIGN.md / the task description).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (config 2: 1e6)")
+    ap.add_argument("--mu", type=float, default=8.5172)
+    ap.add_argument("--sigma", type=float, default=1.1774)
+    ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--time-bins", type=int, default=48)
+    ap.add_argument("--seed", type=int, default=20240601)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-gbases", type=float, default=0.0, help="0 = auto (about 10-20 s of CPU work)")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config4", "config4adv"])
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (a.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pypore_amd import qc, synth
+    from pypore_amd.merge import finalize_distributed
+
+    if a.workload == "config4":
+        a.mu, a.reads = 10.1266, min(a.reads, 200_000)
+    seed = a.seed + 7919 * rank
+    if a.workload == "config4adv":
+        a.reads = min(a.reads, 200_000)
+        lens = synth.adversarial_lengths(a.reads, seed)
+    else:
+        lens = synth.read_lengths(a.reads, a.mu, a.sigma, seed)
+    off = synth.offsets_from_lengths(lens)
+    n_bytes, R = int(off[-1]), len(lens)
+    ch, mux, t = synth.metadata(R, a.channels, a.time_bins, seed)
+    cfg = dict(n_channels=a.channels, n_mux=4, n_time_bins=a.time_bins, bin_seconds=3600, time_mode=0, tz_offset_s=0,
+               ref_time_s=1_528_000_000, fail_q=7.0, max_reads_hint=R)
+    ctx = qc.QCContext(device=local, **cfg)
+
+    # inputs resident in HBM before the timed region
+    d_bases = torch.empty(n_bytes + 64, dtype=torch.uint8, device=dev)
+    d_quals = torch.empty(n_bytes + 64, dtype=torch.uint8, device=dev)
+    ctx.synth_fill_device(d_bases.data_ptr(), d_quals.data_ptr(), 0, n_bytes, seed)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_ch = torch.from_numpy(ch.view(np.int32)).to(dev)
+    d_mux = torch.from_numpy(mux).to(dev)
+    d_t = torch.from_numpy(t).to(dev)
+    ctx.sync()
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.reset()
+        ctx.submit_device(R, n_bytes, d_bases.data_ptr(), d_quals.data_ptr(), d_off.data_ptr(), d_ch.data_ptr(),
+                          d_mux.data_ptr(), d_t.data_ptr())
+        if world > 1:
+            return finalize_distributed(ctx, dist, torch)
+        return ctx.finalize()
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tables = step()
+    ctx.reset_timings()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tables = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tot = torch.tensor([n_bytes], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_bases = int(tot.item())
+    else:
+        total_bases = n_bytes
+    tm = ctx.timings()
+
+    # sanity: the merged tables must account for every read and base of the job
+    assert int(tables["totals"][0]) == R * world, (tables["totals"][0], R * world)
+    assert int(tables["totals"][1]) == total_bases, (tables["totals"][1], total_bases)
+
+    if rank == 0:
+        ms_step = dt / a.steps * 1e3
+        value = total_bases * a.steps / dt / 1e9
+        launches = max(1, tm["tile_kernel_launches"])
+        k_ms = tm["tile_kernel_ms_total"] / launches
+        alg_bytes = tm["tile_kernel_bytes"] / launches      # 2*B + 50*R per launch (BASELINE.md accounting)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "Gbases/s per-read QC stats", "value": round(value, 2), "unit": "Gbases/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s: %d reads/GPU, lognormal(mu=%.4f, sigma=%.4f) clipped [1, 2e6], %.2f Gbases + "
+                                   "quals per GPU, %d channels, %d hourly bins, tables + radix-sort N50 included"
+                                   % (a.workload, R, a.mu, a.sigma, n_bytes / 1e9, a.channels, a.time_bins),
+                       "reads_per_gpu": R, "bases_per_gpu": n_bytes, "n50": int(tables["n50"]),
+                       "kernel_only_gbases_per_s_per_gpu": round(n_bytes / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
+                       "finalize_ms": round(tm["finalize_ms_last"], 3), "sort_ms": round(tm["sort_ms_last"], 3)},
+            "roofline": {"bound": "hbm", "kernel": "tile_kernel", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": None, "kernel_ms": round(k_ms, 4), "bytes_per_launch": int(alg_bytes)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a, off, d_bases, d_quals, ctx)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, off, d_bases, d_quals, ctx):
+    """The C oracle ("port" of the reference's per-read arithmetic) on the host cores, on a bounded prefix of
+    the same workload; also re-checks the GPU records of that prefix against it."""
+    from oracle import c_oracle as co
+    cores = min(16, os.cpu_count() or 1)
+    target = a.cpu_sample_gbases * 1e9 if a.cpu_sample_gbases > 0 else 0.35e9 * cores   # ~10-20 s at ~0.03 Gb/s/core..
+    r = int(np.searchsorted(off, np.uint64(target), side="right")) - 1
+    r = max(1, min(r, len(off) - 1))
+    nb = int(off[r])
+    hb = d_bases[:nb].cpu().numpy()
+    hq = d_quals[:nb].cpu().numpy()
+    sub = off[: r + 1].copy()
+    t0 = time.perf_counter()
+    want = co.per_read(hb, hq, sub, nthreads=cores)
+    dt = time.perf_counter() - t0
+    got = ctx.read_stats(0, r)
+    ok = all(np.array_equal(got[k], want[k]) for k in ("length", "gc", "n", "qsum"))
+    ok = ok and [(int(h) << 32) + int(l) for h, l in zip(got["err_hi"], got["err_lo"])] == [int(e) for e in want["err"]]
+    return {"value": round(nb / dt / 1e9, 3), "unit": "Gbases/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads (%.2f Gbases) of the same workload, oracle/ppqc_oracle.c per-read statistics, "
+                      "%d pthreads, %.1f s" % (r, nb / 1e9, cores, dt),
+            "gpu_matches_cpu_on_sample": bool(ok)}
+
+
+if __name__ == "__main__":
+    main()

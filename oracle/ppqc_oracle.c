@@ -48,6 +48,7 @@ typedef struct {
     uint64_t *err_hi, *err_lo;
     double *mean_q;
     const uint64_t *lut;
+    const uint8_t *cls;
 } job_t;
 
 static void *per_read_worker(void *arg) {
@@ -57,14 +58,19 @@ static void *per_read_worker(void *arg) {
         uint32_t gc = 0, nn = 0;
         uint64_t qs = 0;
         u128 S = 0;
-        for (uint64_t i = a; i < b; ++i) {
-            /* GC(): sum of seq.count(x) for x in "GCgcSs"; N count: 'N' + 'n' */
-            uint8_t c = j->bases[i];
-            gc += (c == 'G') + (c == 'C') + (c == 'g') + (c == 'c') + (c == 'S') + (c == 's');
-            nn += (c == 'N') + (c == 'n');
-            uint8_t q = j->quals[i];
-            qs += q;
-            S += j->lut[q];
+        /* GC(): sum of seq.count(x) for x in "GCgcSs"; N count: 'N' + 'n' (class table = the same predicate).
+         * The fixed-point sum is folded into 128 bits every 2048 bytes (2^11 * 2^52 < 2^64). */
+        for (uint64_t i = a; i < b;) {
+            uint64_t e = i + 2048 < b ? i + 2048 : b, s64 = 0;
+            for (; i < e; ++i) {
+                uint8_t k = j->cls[j->bases[i]];
+                gc += k & 1u;
+                nn += k >> 1;
+                uint8_t q = j->quals[i];
+                qs += q;
+                s64 += j->lut[q];
+            }
+            S += s64;
         }
         uint64_t L = b - a;
         j->len[r] = (uint32_t)L;
@@ -83,7 +89,11 @@ void orc_per_read(const uint8_t *bases, const uint8_t *quals, const uint64_t *of
                   uint32_t *gc, uint32_t *n, int64_t *qsum, uint64_t *err_hi, uint64_t *err_lo, double *mean_q,
                   int nthreads) {
     uint64_t lut[256];
+    uint8_t cls[256];
     orc_err_lut(lut);
+    for (int c = 0; c < 256; ++c)
+        cls[c] = (uint8_t)(((c == 'G') | (c == 'C') | (c == 'g') | (c == 'c') | (c == 'S') | (c == 's')) |
+                           (((c == 'N') | (c == 'n')) << 1));
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
     pthread_t th[256];
@@ -95,7 +105,7 @@ void orc_per_read(const uint8_t *bases, const uint8_t *quals, const uint64_t *of
         uint64_t r1 = r;
         if (t == nthreads - 1) r1 = R;
         else while (r1 < R && off[r1 + 1] <= target) ++r1;
-        jobs[t] = (job_t){bases, quals, off, r, r1, len, gc, n, qsum, err_hi, err_lo, mean_q, lut};
+        jobs[t] = (job_t){bases, quals, off, r, r1, len, gc, n, qsum, err_hi, err_lo, mean_q, lut, cls};
         r = r1;
     }
     for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, per_read_worker, &jobs[t]);

@@ -80,6 +80,22 @@ class Timing(C.Structure):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so.7; if this library pulled in
+    /opt/rocm's copy first, a later `import torch` would bring up a second runtime that finds no GPU.  Loading
+    torch's copy first (same soname) makes both resolve to it.  Without torch the system copy is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load libpypore_qc.so, failing loudly if it has not been built (python __graft_entry__.py build)."""
     global _lib
@@ -88,6 +104,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     lib.ppqc_last_error.restype = C.c_char_p
     P = C.c_void_p
