@@ -1,0 +1,70 @@
+"""N > 1 path on CPU: two processes, gloo backend.  'N shards merged == 1 shard over the concatenation' for every
+mergeable table, the extremes and N50 (all-gather of lengths), using the same merge routines bench.py uses with RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from util import random_batch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    import torch
+    import torch.distributed as dist
+    from oracle import pypore_oracle as po, c_oracle as co
+    from pypore_amd import merge
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = dict(n_channels=24, n_mux=4, n_time_bins=72, bin_seconds=3600, time_mode=0, tz_offset_s=0,
+                   ref_time_s=1_528_000_000, fail_q=7.0)
+        b = random_batch(77, 3001, 150, n_channels=24, hours=75)
+        R = len(b["channel"])
+        cut = [0, R // 3, R][rank:rank + 2]       # uneven contiguous shards
+        a, e = cut
+        o = b["offsets"][a:e + 1]
+        st = co.per_read(b["bases"][int(o[0]):int(o[-1])], b["quals"][int(o[0]):int(o[-1])], o - o[0], 2)
+        meta = (b["channel"][a:e], b["mux"][a:e], b["time"][a:e], b["fail_flag"][a:e])
+        # phase 1: local extremes -> all-reduce MAX / MIN
+        loc = co.tables(st, *meta, cfg)
+        t_max = torch.from_numpy(np.concatenate(([loc["max_len"]], loc["chan_max_len"])).astype(np.int64))
+        t_min = torch.from_numpy(np.concatenate(([loc["min_pos_len"]], loc["chan_min_len"])).astype(np.int64))
+        keys = ("totals", "len_hist_log2", "q_hist", "gc_hist", "hour_reads", "hour_bases", "chan_reads", "chan_bases",
+                "chan_fail", "cmh_reads", "cmh_bases")
+        t_sum = torch.from_numpy(np.concatenate([np.asarray(loc[k]).reshape(-1) for k in keys]).astype(np.int64))
+        merge.allreduce_table_tensors(t_sum, t_max, t_min, dist)
+        lens = np.where((meta[0] >= 1) & (meta[0] <= 24) & (meta[3] == 0), st["length"], 0).astype(np.int32)
+        all_lens = merge.gather_lengths(torch.from_numpy(lens), dist, torch)
+        # reference: one shard over the concatenation
+        full = co.per_read(b["bases"], b["quals"], b["offsets"], 2)
+        want = co.tables(full, b["channel"], b["mux"], b["time"], b["fail_flag"], cfg)
+        wsum = np.concatenate([np.asarray(want[k]).reshape(-1) for k in keys]).astype(np.int64)
+        assert np.array_equal(t_sum.numpy(), wsum)
+        assert int(t_max[0]) == want["max_len"] and np.array_equal(t_max[1:].numpy(), want["chan_max_len"])
+        assert int(t_min[0]) == want["min_pos_len"] and np.array_equal(t_min[1:].numpy(), want["chan_min_len"])
+        assert all_lens.numel() == 2 * max(R // 3, R - R // 3)
+        assert co.n50(all_lens.numpy().astype(np.uint32)) == want["n50"]
+        hm = merge.merge_tables_host([loc, loc])
+        assert np.array_equal(hm["chan_reads"], 2 * np.asarray(loc["chan_reads"]))
+        open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_merge_equals_single_shard(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
