@@ -13,9 +13,13 @@
 // segment sums are differences of prefixes (all quantities are integers, so this is exact).  Ultra-long reads are
 // thereby split over as many wavefronts as they have tiles; each wave writes a head/tail partial per tile and
 // finalize_reads merges them in tile order.  Everything is integer, so results do not depend on the decomposition.
+#include <stdlib.h>
+
 #include "ppqc_internal.hpp"
 
 namespace ppqc {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct Acc {
     uint32_t gcs, n, qb;
@@ -130,7 +134,7 @@ __device__ __forceinline__ void flush(Acc& acc, int lane, uint64_t* cnt, uint64_
     acc = Acc{0, 0, 0, 0};
 }
 
-template <int NB>
+template <int NB, bool NT>
 __global__ __launch_bounds__(256) void tile_kernel(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra,
                                                    uint64_t read_base, Partial* __restrict__ head,
                                                    Partial* __restrict__ tail, uint64_t n_tiles) {
@@ -167,8 +171,15 @@ __global__ __launch_bounds__(256) void tile_kernel(BatchView b, const uint64_t* 
             for (int i = 0; i < NB; ++i) {
                 uint32_t o = (s0 + i) * kSpan + lane_off;
                 o = o < last_vec ? o : last_vec;   // clamp instead of predicating: out-of-range lanes are masked below
-                vb[i] = *reinterpret_cast<const uint4*>(pb + o);
-                vq[i] = *reinterpret_cast<const uint4*>(pq + o);
+                if (NT) {   // read-once streams: nontemporal loads keep them out of the way of offsets / LUT lines
+                    const u32x4 tb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pb + o));
+                    const u32x4 tq = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pq + o));
+                    vb[i] = make_uint4(tb[0], tb[1], tb[2], tb[3]);
+                    vq[i] = make_uint4(tq[0], tq[1], tq[2], tq[3]);
+                } else {
+                    vb[i] = *reinterpret_cast<const uint4*>(pb + o);
+                    vq[i] = *reinterpret_cast<const uint4*>(pq + o);
+                }
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
@@ -275,17 +286,42 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
     ra.flags[g] = flags;
 }
 
+template <int NB, bool NT>
+static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
+                                      Partial* head, Partial* tail, int n_cu, int blocks_per_cu, hipStream_t s) {
+    const uint64_t n_tiles = (b.n_bytes + kTile - 1) / kTile;
+    // persistent grid sized to what is resident at once (a larger grid would run in two uneven rounds),
+    // never more waves than tiles
+    int occ = 0;
+    if (blocks_per_cu <= 0) {
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tile_kernel<NB, NT>, 256, 0);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = occ > 0 ? occ : 4;
+    }
+    uint64_t blocks = (n_tiles + 3) / 4;
+    const uint64_t cap = (uint64_t)n_cu * blocks_per_cu;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((tile_kernel<NB, NT>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head,
+                       tail, n_tiles);
+    return hipGetLastError();
+}
+
+// PPQC_TILE_VARIANT / PPQC_TILE_BLOCKS_PER_CU are tuning knobs for A/B measurements; the default is the shipped one.
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
                               Partial* head, Partial* tail, int n_cu, hipStream_t s) {
     if (b.n_bytes == 0 || b.n_reads == 0) return hipSuccess;
-    const uint64_t n_tiles = (b.n_bytes + kTile - 1) / kTile;
-    // persistent grid: up to 8 blocks of 4 waves per CU, never more waves than tiles
-    uint64_t blocks = (n_tiles + 3) / 4;
-    const uint64_t cap = (uint64_t)n_cu * 8;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(tile_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head, tail,
-                       n_tiles);
-    return hipGetLastError();
+    const char* v = getenv("PPQC_TILE_VARIANT");
+    const char* bp = getenv("PPQC_TILE_BLOCKS_PER_CU");
+    const int bpc = bp ? atoi(bp) : 0;
+    const int variant = v ? atoi(v) : 0;
+    switch (variant) {
+        case 1: return launch_tile_variant<4, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        case 2: return launch_tile_variant<8, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        case 3: return launch_tile_variant<8, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        case 4: return launch_tile_variant<2, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        case 5: return launch_tile_variant<2, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        default: return launch_tile_variant<4, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+    }
 }
 
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,

@@ -1,0 +1,51 @@
+"""A/B of tile-kernel variants in ONE process, interleaved rounds (guide rule 24). GPU box only.
+usage: python tools/tile_ab.py [reads] [rounds]"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pypore_amd import qc, synth
+
+reads = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+variants = os.environ.get("AB_VARIANTS", "0,1,2,3,4,5").split(",")
+bpcs = os.environ.get("AB_BPC", "0").split(",")
+workload = os.environ.get("AB_WORKLOAD", "config2")
+seed = 20240601
+if workload == "adv":
+    lens = synth.adversarial_lengths(reads, seed)
+elif workload == "config4":
+    lens = synth.read_lengths(reads, 10.1266, 1.1774, seed)
+elif workload == "short":
+    lens = synth.read_lengths(reads, 6.0, 1.0, seed)
+else:
+    lens = synth.read_lengths(reads, 8.5172, 1.1774, seed)
+off = synth.offsets_from_lengths(lens); nb = int(off[-1]); R = len(lens)
+ch, mux, t = synth.metadata(R, 512, 48, seed)
+ctx = qc.QCContext(device=0, ref_time_s=1_528_000_000, max_reads_hint=R)
+db = torch.empty(nb + 64, dtype=torch.uint8, device="cuda"); dq = torch.empty(nb + 64, dtype=torch.uint8, device="cuda")
+ctx.synth_fill_device(db.data_ptr(), dq.data_ptr(), 0, nb, seed)
+d = [torch.from_numpy(x).cuda() for x in (off.view(np.int64), ch.view(np.int32), mux, t)]
+ctx.sync()
+res = {}
+ref = None
+for rnd in range(rounds + 1):
+    for v in variants:
+        for bpc in bpcs:
+            os.environ["PPQC_TILE_VARIANT"] = v
+            os.environ["PPQC_TILE_BLOCKS_PER_CU"] = bpc
+            ctx.reset(); ctx.reset_timings()
+            ctx.submit_device(R, nb, db.data_ptr(), dq.data_ptr(), *[x.data_ptr() for x in d])
+            tm = ctx.timings()
+            if rnd == 0:
+                s = ctx.read_stats(0, min(R, 20000))
+                sig = (int(s["gc"].sum()), int(s["qsum"].sum()), int(s["err_lo"].sum() & 0xFFFFFFFFFFFF), int(s["n"].sum()))
+                ref = ref or sig
+                assert sig == ref, (v, bpc, sig, ref)
+                continue
+            res.setdefault((v, bpc), []).append(tm["tile_kernel_ms_total"])
+bytes_alg = 2 * nb + 50 * R
+print("workload %s reads %d bases %.2f G" % (workload, R, nb / 1e9))
+for k, ms in sorted(res.items(), key=lambda kv: np.median(kv[1])):
+    med, mn = float(np.median(ms)), float(min(ms))
+    print("variant %s bpc %s: median %.3f ms (%.0f GB/s, %.3f of 8 TB/s)  min %.3f ms" % (k[0], k[1], med, bytes_alg / med / 1e6, bytes_alg / med / 1e6 / 8000, mn))
