@@ -1,6 +1,7 @@
 // Host side of libpypore_qc.so: the extern "C" entry points of include/pypore_qc.h.
 // Owns all device memory, one compute stream and two copy streams (double-buffered H2D) per context.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -62,6 +63,8 @@ struct ppqc_ctx {
 
     Slot slot[2];
 
+    // one device allocation [sum | max | min | tmin tmax | n50 total], mirrored by one pinned host buffer
+    uint64_t *res_buf = nullptr, *res_host = nullptr, res_words = 0;
     uint64_t *sum_buf = nullptr, *max_buf = nullptr, *min_buf = nullptr, *n50_out = nullptr;
     int64_t* tminmax = nullptr;
     int state = 0;   // 0 reads only, 1 extremes done, 2 tables done, 3 n50 done
@@ -251,11 +254,15 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     tp.ref_time_s = cfg->ref_time_s; tp.fail_q = cfg->fail_q; tp.thr_fail = q_threshold(cfg->fail_q);
     for (int j = 0; j <= PPQC_N_QHIST; ++j) tp.thr_q[j] = q_threshold(6.0 + j);
 
-    HIPCHK(hipMalloc((void**)&c->sum_buf, tp.lay.n_sum * 8));
-    HIPCHK(hipMalloc((void**)&c->max_buf, (1 + (uint64_t)cfg->n_channels) * 8));
-    HIPCHK(hipMalloc((void**)&c->min_buf, (1 + (uint64_t)cfg->n_channels) * 8));
-    HIPCHK(hipMalloc((void**)&c->tminmax, 16));
-    HIPCHK(hipMalloc((void**)&c->n50_out, 16));
+    const uint64_t nch1 = 1 + (uint64_t)cfg->n_channels;
+    c->res_words = tp.lay.n_sum + 2 * nch1 + 4;
+    HIPCHK(hipMalloc((void**)&c->res_buf, c->res_words * 8));
+    HIPCHK(hipHostMalloc((void**)&c->res_host, c->res_words * 8, hipHostMallocDefault));
+    c->sum_buf = c->res_buf;
+    c->max_buf = c->sum_buf + tp.lay.n_sum;
+    c->min_buf = c->max_buf + nch1;
+    c->tminmax = (int64_t*)(c->min_buf + nch1);
+    c->n50_out = c->min_buf + nch1 + 2;
     HIPCHK(hipMalloc((void**)&c->chan_start, (uint64_t)cfg->n_channels * 4 + 64));
     HIPCHK(hipMalloc((void**)&c->first_desc, (uint64_t)cfg->n_channels * 4 + 64));
     if (cfg->max_reads_hint) CHK(ensure_reads(c, cfg->max_reads_hint));
@@ -269,10 +276,10 @@ int ppqc_destroy(ppqc_ctx* c) {
     (void)hipDeviceSynchronize();
     ReadArrays& r = c->ra;
     void* ptrs[] = {r.rec_cnt, r.rec_hi, r.rec_lo, r.len, r.gc, r.nn, r.qsum, r.mean_q, r.err_hi, r.err_lo, r.flags,
-                    r.channel, r.mux, r.time, r.hour, r.lens32, c->head, c->tail, c->sum_buf, c->max_buf, c->min_buf,
-                    c->tminmax, c->n50_out, c->sk32, c->sk32_tmp, c->counts, c->vals, c->vals_tmp, c->sk64,
+                    r.channel, r.mux, r.time, r.hour, r.lens32, c->head, c->tail, c->res_buf, c->sk32, c->sk32_tmp, c->counts, c->vals, c->vals_tmp, c->sk64,
                     c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->res_host) (void)hipHostFree(c->res_host);
     for (int i = 0; i < 2; ++i) {
         Slot& s = c->slot[i];
         void* sp[] = {s.bases, s.quals, s.mux, s.ff, s.offsets, s.channel, s.time};
@@ -314,14 +321,15 @@ int ppqc_free_pinned(void* p) {
 static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     const uint64_t R = b->n_reads;
     CHK(ensure_reads(c, c->n_reads + R));
-    const uint64_t n_tiles = (b->n_bytes + kTile - 1) / kTile;
+    uint32_t shift = kDefaultTileShift;
+    if (const char* e = getenv("PPQC_TILE_SHIFT")) shift = (uint32_t)atoi(e);   // tuning knob for A/B runs
+    if (shift < (uint32_t)kMinTileShift || shift > (uint32_t)kMaxTileShift) shift = kDefaultTileShift;
+    const uint64_t n_tiles = (b->n_bytes + (1ull << shift) - 1) >> shift;
     CHK(ensure_tiles(c, n_tiles));
     const uint64_t base = c->n_reads;
     hipStream_t s = c->stream;
-    HIPCHK(hipMemcpyAsync(c->ra.channel + base, b->channel, R * 4, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->ra.mux + base, b->mux, R, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->ra.time + base, b->start_time_s, R * 8, hipMemcpyDeviceToDevice, s));
-    BatchView v{b->bases, b->quals, b->offsets, R, b->n_bytes, b->fail_flag};
+    BatchView v{b->bases, b->quals, b->offsets, R, b->n_bytes, b->fail_flag, shift, b->channel, b->mux,
+                b->start_time_s};
     EvPair ev{get_event(c), get_event(c), 2 * b->n_bytes + 50 * R};
     if (!ev.a || !ev.b) return fail(PPQC_E_HIP, "hipEventCreate failed");
     HIPCHK(hipEventRecord(ev.a, s));
@@ -367,7 +375,7 @@ int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
     if (b->offsets[0] != 0) return fail(PPQC_E_INVALID, "offsets[0] must be 0");
     for (uint64_t i = 0; i < R; ++i) {
         if (b->offsets[i + 1] < b->offsets[i]) return fail(PPQC_E_INVALID, "offsets not monotone");
-        if (b->offsets[i + 1] - b->offsets[i] >= (1ull << 32)) return fail(PPQC_E_RANGE, "read longer than 2^32-1");
+        if (b->offsets[i + 1] - b->offsets[i] >= 0xFFFFFFFFull) return fail(PPQC_E_RANGE, "read longer than 2^32-2");
     }
     if (b->offsets[R] != b->n_bytes) return fail(PPQC_E_INVALID, "offsets[n_reads] != n_bytes");
     HIPCHK(hipSetDevice(c->device));
@@ -463,13 +471,8 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const uint64_t nch1 = 1 + (uint64_t)c->cfg.n_channels;
     HIPCHK(hipEventRecord(c->ev_t0, s));
-    HIPCHK(hipMemsetAsync(c->max_buf, 0, nch1 * 8, s));
-    HIPCHK(launch_fill_u64(c->min_buf, nch1, (uint64_t)INT64_MAX, s));
-    const int64_t init[2] = {INT64_MAX, INT64_MIN};
-    HIPCHK(hipMemcpyAsync(c->tminmax, init, 16, hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));   // init[] is on the host stack
+    HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum, 1 + (uint64_t)c->cfg.n_channels, s));
     HIPCHK(launch_extremes(c->ra, c->n_reads, c->tp, c->max_buf, c->min_buf, c->tminmax, s));
     c->state = 1;
     return PPQC_OK;
@@ -488,7 +491,6 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const uint64_t n = c->n_reads;
-    HIPCHK(hipMemsetAsync(c->sum_buf, 0, c->tp.lay.n_sum * 8, s));
     if (c->cfg.time_mode == 1 && n) {
         int64_t tmm[2];
         HIPCHK(hipMemcpyAsync(tmm, c->tminmax, 16, hipMemcpyDeviceToHost, s));
@@ -517,9 +519,9 @@ int ppqc_finalize_n50(ppqc_ctx* c, const uint32_t* dlens, uint64_t n) {
     if (!dlens) { dlens = c->ra.lens32; n = c->n_reads; }
     if (n >= (1ull << 32)) return fail(PPQC_E_RANGE, "more than 2^32-1 lengths");
     HIPCHK(hipEventRecord(c->ev_s0, s));
-    uint64_t maxlen = 0;
-    HIPCHK(hipMemcpyAsync(&maxlen, c->max_buf, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(c->res_host + c->tp.lay.n_sum, c->max_buf, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    const uint64_t maxlen = c->res_host[c->tp.lay.n_sum];
     CHK(ensure_sort32(c, n ? n : 1));
     if (n) HIPCHK(hipMemcpyAsync(c->sk32, dlens, n * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(sort_u32(c->sk32, c->sk32_tmp, n, c->counts, bytes_mask_for(maxlen), s));
@@ -535,10 +537,11 @@ int ppqc_fetch_tables(ppqc_ctx* c, ppqc_tables* o) {
     if (c->state < 3) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes/tables/n50 first");
     CHK(ppqc_sync(c));
     const TableLayout& l = c->tp.lay;
-    std::vector<uint64_t> h(l.n_sum);
-    HIPCHK(hipMemcpy(h.data(), c->sum_buf, l.n_sum * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, c->res_words * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint64_t* h = c->res_host;
     const uint64_t nch = l.n_channels, nb = l.n_time_bins, cells = nch * l.n_mux * nb;
-#define OUT(dst, off, cnt) if (dst) memcpy(dst, h.data() + (off), (cnt) * 8)
+#define OUT(dst, off, cnt) if (dst) memcpy(dst, h + (off), (cnt) * 8)
     OUT(o->totals, l.off_totals, PPQC_N_TOTALS); OUT(o->len_hist_log2, l.off_len_log2, PPQC_N_LEN_LOG2);
     OUT(o->len_hist_lin, l.off_len_lin, PPQC_N_LEN_LIN); OUT(o->q_hist, l.off_q_hist, PPQC_N_QHIST);
     OUT(o->gc_hist, l.off_gc_hist, PPQC_N_GCHIST); OUT(o->hour_reads, l.off_hour_reads, nb);
@@ -546,17 +549,14 @@ int ppqc_fetch_tables(ppqc_ctx* c, ppqc_tables* o) {
     OUT(o->chan_bases, l.off_chan_bases, nch); OUT(o->chan_fail, l.off_chan_fail, nch);
     OUT(o->cmh_reads, l.off_cmh_reads, cells); OUT(o->cmh_bases, l.off_cmh_bases, cells);
 #undef OUT
-    std::vector<uint64_t> mx(1 + nch), mn(1 + nch);
-    HIPCHK(hipMemcpy(mx.data(), c->max_buf, (1 + nch) * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(mn.data(), c->min_buf, (1 + nch) * 8, hipMemcpyDeviceToHost));
-    if (o->chan_max_len) memcpy(o->chan_max_len, mx.data() + 1, nch * 8);
-    if (o->chan_min_len) memcpy(o->chan_min_len, mn.data() + 1, nch * 8);
+    const uint64_t* mx = h + l.n_sum;
+    const uint64_t* mn = mx + 1 + nch;
+    if (o->chan_max_len) memcpy(o->chan_max_len, mx + 1, nch * 8);
+    if (o->chan_min_len) memcpy(o->chan_min_len, mn + 1, nch * 8);
     o->max_len = mx[0];
     o->min_pos_len = mn[0];
     o->lin_bin_width = mx[0] / PPQC_N_LEN_LIN + 1;
-    uint64_t n50[2];
-    HIPCHK(hipMemcpy(n50, c->n50_out, 16, hipMemcpyDeviceToHost));
-    o->n50 = c->n50 = n50[0];
+    o->n50 = c->n50 = (mn + 1 + nch)[2];
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1) == hipSuccess) c->timing.finalize_ms_last = ms;
     if (hipEventElapsedTime(&ms, c->ev_s0, c->ev_s1) == hipSuccess) c->timing.sort_ms_last = ms;

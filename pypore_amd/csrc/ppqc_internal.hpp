@@ -10,8 +10,9 @@ namespace ppqc {
 constexpr int kWave = 64;               // CDNA wavefront
 constexpr int kVec = 16;                // bytes per lane per global_load_dwordx4
 constexpr int kSpan = kWave * kVec;     // 1 KiB: one wave-wide load of one stream
-constexpr int kTileSpans = 64;          // spans per tile
-constexpr uint64_t kTile = (uint64_t)kSpan * kTileSpans;   // 64 KiB of each stream per tile
+constexpr int kMaxTileShift = 16;        // tiles are 2^shift bytes of each stream, 4 KiB .. 64 KiB (packed counters
+constexpr int kMinTileShift = 12;        // and per-lane u64 error sums are sized for <= 64 KiB)
+constexpr int kDefaultTileShift = 16;
 
 // A partial (or complete) per-read sum produced by one wave for one tile.
 //   cnt : packed counters  [0,26) sum of quality bytes, [26,44) N count, [44,62) G/C/S count
@@ -35,6 +36,10 @@ struct BatchView {
     const uint64_t* offsets;   // n_reads + 1, offsets[0] == 0
     uint64_t n_reads, n_bytes;
     const uint8_t* fail_flag;  // may be null
+    uint32_t tile_shift;       // log2 of the tile size in bytes
+    const uint32_t* channel;   // per-read metadata of the batch, copied into the run arrays by finalize_reads
+    const uint8_t* mux;
+    const int64_t* time;
 };
 
 // Per-read record arrays of the context (device, capacity >= n_reads of the whole run).
@@ -80,6 +85,8 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
                          hipStream_t s);
 
 hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s);
+// res = [n_sum sums = 0 | nch1 max = 0 | nch1 min = INT64_MAX | tmin = INT64_MAX, tmax = INT64_MIN | n50, total = 0]
+hipError_t launch_init_results(uint64_t* res, uint64_t n_sum, uint64_t nch1, hipStream_t s);
 
 // time_mode 1 helpers
 hipError_t launch_mode1_keys(ReadArrays ra, uint64_t n, const TableParams& tp, const int64_t* tminmax, uint64_t* keys,

@@ -19,13 +19,21 @@ __device__ __forceinline__ int32_t hour_of_day(int64_t t, const TableParams& tp)
 }
 
 // ---- pass 1: extremes, sort input, absolute hour bins --------------------------------------------------------------
+// Per-channel min/max are privatised in LDS (u32 pairs, dynamic: 8 B per channel) when they fit, and flushed once per
+// block; run extremes go through thread-local registers, one LDS atomic per thread, one global atomic per block.
 __global__ __launch_bounds__(256) void extremes_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* max_buf,
-                                                       uint64_t* min_buf, int64_t* tminmax) {
+                                                       uint64_t* min_buf, int64_t* tminmax, uint32_t nchL) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* s_cmax = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* s_cmin = s_cmax + nchL;
     __shared__ unsigned long long s_max, s_min;
     __shared__ long long s_tmin, s_tmax;
     if (threadIdx.x == 0) { s_max = 0; s_min = (unsigned long long)INT64_MAX; s_tmin = INT64_MAX; s_tmax = INT64_MIN; }
+    for (uint32_t k = threadIdx.x; k < nchL; k += blockDim.x) { s_cmax[k] = 0; s_cmin[k] = 0xFFFFFFFFu; }
     __syncthreads();
     const uint32_t nch = tp.lay.n_channels;
+    unsigned long long lmax = 0, lmin = (unsigned long long)INT64_MAX;
+    long long tmin = INT64_MAX, tmax = INT64_MIN;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t ch = ra.channel[i];
         const bool good = ch >= 1 && ch <= nch;
@@ -33,13 +41,18 @@ __global__ __launch_bounds__(256) void extremes_kernel(ReadArrays ra, uint64_t n
         ra.lens32[i] = good ? L : 0;
         int32_t hour = -1;
         if (good) {
-            atomicMax(&s_max, (unsigned long long)L);
-            if (L > 0) atomicMin(&s_min, (unsigned long long)L);
-            atomicMax((unsigned long long*)&max_buf[ch], (unsigned long long)L);
-            atomicMin((unsigned long long*)&min_buf[ch], (unsigned long long)L);
+            lmax = L > lmax ? L : lmax;
+            if (L > 0 && L < lmin) lmin = L;
+            if (nchL) {
+                atomicMax(&s_cmax[ch - 1], L);
+                atomicMin(&s_cmin[ch - 1], L);
+            } else {
+                atomicMax((unsigned long long*)&max_buf[ch], (unsigned long long)L);
+                atomicMin((unsigned long long*)&min_buf[ch], (unsigned long long)L);
+            }
             const int64_t t = ra.time[i];
-            atomicMin(&s_tmin, (long long)t);
-            atomicMax(&s_tmax, (long long)t);
+            tmin = t < tmin ? t : tmin;
+            tmax = t > tmax ? t : tmax;
             if (tp.time_mode == 0) {
                 const int64_t h = floordiv64(t - tp.ref_time_s + tp.tz_offset_s, (int64_t)tp.bin_seconds);
                 hour = (h >= 0 && h < (int64_t)tp.lay.n_time_bins) ? (int32_t)h : -1;
@@ -47,7 +60,16 @@ __global__ __launch_bounds__(256) void extremes_kernel(ReadArrays ra, uint64_t n
         }
         if (tp.time_mode == 0) ra.hour[i] = hour;
     }
+    if (lmax) atomicMax(&s_max, lmax);
+    if (lmin != (unsigned long long)INT64_MAX) atomicMin(&s_min, lmin);
+    if (tmin != INT64_MAX) { atomicMin(&s_tmin, tmin); atomicMax(&s_tmax, tmax); }
     __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nchL; k += blockDim.x) {
+        if (s_cmin[k] != 0xFFFFFFFFu) {   // channel seen by this block
+            atomicMax((unsigned long long*)&max_buf[1 + k], (unsigned long long)s_cmax[k]);
+            atomicMin((unsigned long long*)&min_buf[1 + k], (unsigned long long)s_cmin[k]);
+        }
+    }
     if (threadIdx.x == 0) {
         atomicMax((unsigned long long*)&max_buf[0], s_max);
         atomicMin((unsigned long long*)&min_buf[0], s_min);
@@ -222,6 +244,24 @@ hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s) {
     return hipGetLastError();
 }
 
+__global__ void init_results_kernel(uint64_t* res, uint64_t n_sum, uint64_t nch1) {
+    const uint64_t total = n_sum + 2 * nch1 + 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t v = 0;
+        if (i >= n_sum + nch1 && i < n_sum + 2 * nch1) v = (uint64_t)INT64_MAX;          // min section
+        else if (i == n_sum + 2 * nch1) v = (uint64_t)INT64_MAX;                         // tmin
+        else if (i == n_sum + 2 * nch1 + 1) v = (uint64_t)INT64_MIN;                     // tmax
+        res[i] = v;
+    }
+}
+hipError_t launch_init_results(uint64_t* res, uint64_t n_sum, uint64_t nch1, hipStream_t s) {
+    const uint64_t total = n_sum + 2 * nch1 + 4;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(init_results_kernel, dim3((unsigned)blocks), dim3(256), 0, s, res, n_sum, nch1);
+    return hipGetLastError();
+}
+
 static inline unsigned grid_for(uint64_t n, unsigned cap) {
     uint64_t b = (n + 255) / 256;
     if (b < 1) b = 1;
@@ -231,7 +271,10 @@ static inline unsigned grid_for(uint64_t n, unsigned cap) {
 hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* max_buf, uint64_t* min_buf,
                            int64_t* tminmax, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(extremes_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, s, ra, n, tp, max_buf, min_buf, tminmax);
+    // a length of 2^32-1 cannot be told from "unseen" in the u32 LDS copy: lengths are < 2^32-1 by the API contract
+    const uint32_t nchL = tp.lay.n_channels <= 8192 ? tp.lay.n_channels : 0;
+    hipLaunchKernelGGL(extremes_kernel, dim3(grid_for(n, 512)), dim3(256), (size_t)nchL * 8, s, ra, n, tp, max_buf,
+                       min_buf, tminmax, nchL);
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@ reads = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 variants = os.environ.get("AB_VARIANTS", "0,1,2,3,4,5").split(",")
 bpcs = os.environ.get("AB_BPC", "0").split(",")
+shifts = os.environ.get("AB_SHIFT", "16").split(",")
 workload = os.environ.get("AB_WORKLOAD", "config2")
 seed = 20240601
 if workload == "adv":
@@ -31,9 +32,10 @@ res = {}
 ref = None
 for rnd in range(rounds + 1):
     for v in variants:
-        for bpc in bpcs:
+        for bpc, sh in [(x, y) for x in bpcs for y in shifts]:
             os.environ["PPQC_TILE_VARIANT"] = v
             os.environ["PPQC_TILE_BLOCKS_PER_CU"] = bpc
+            os.environ["PPQC_TILE_SHIFT"] = sh
             ctx.reset(); ctx.reset_timings()
             ctx.submit_device(R, nb, db.data_ptr(), dq.data_ptr(), *[x.data_ptr() for x in d])
             tm = ctx.timings()
@@ -41,11 +43,11 @@ for rnd in range(rounds + 1):
                 s = ctx.read_stats(0, min(R, 20000))
                 sig = (int(s["gc"].sum()), int(s["qsum"].sum()), int(s["err_lo"].sum() & 0xFFFFFFFFFFFF), int(s["n"].sum()))
                 ref = ref or sig
-                assert sig == ref, (v, bpc, sig, ref)
+                assert sig == ref, (v, bpc, sh, sig, ref)
                 continue
-            res.setdefault((v, bpc), []).append(tm["tile_kernel_ms_total"])
+            res.setdefault((v, bpc, sh), []).append(tm["tile_kernel_ms_total"])
 bytes_alg = 2 * nb + 50 * R
 print("workload %s reads %d bases %.2f G" % (workload, R, nb / 1e9))
 for k, ms in sorted(res.items(), key=lambda kv: np.median(kv[1])):
     med, mn = float(np.median(ms)), float(min(ms))
-    print("variant %s bpc %s: median %.3f ms (%.0f GB/s, %.3f of 8 TB/s)  min %.3f ms" % (k[0], k[1], med, bytes_alg / med / 1e6, bytes_alg / med / 1e6 / 8000, mn))
+    print("variant %s bpc %s shift %s: median %.3f ms (%.0f GB/s, %.3f of 8 TB/s)  min %.3f ms" % (k[0], k[1], k[2], med, bytes_alg / med / 1e6, bytes_alg / med / 1e6 / 8000, mn))
