@@ -30,7 +30,7 @@ enum {
     PPQC_E_HIP = -3,       /* a HIP runtime call failed (message has the hipError string) */
     PPQC_E_NOMEM = -4,
     PPQC_E_STATE = -5,     /* call order violated (e.g. fetch before finalize) */
-    PPQC_E_RANGE = -6      /* input outside the documented range (e.g. time_mode 1 with a >2^32 s span) */
+    PPQC_E_RANGE = -6      /* input outside the documented range (e.g. time_mode 1 with a span of 2^40 ticks or more) */
 };
 
 /* fixed-point scale of the error-probability sum: e[b] = round(2^52 * 10^(-(b-33)/10)) */
@@ -67,14 +67,16 @@ typedef struct ppqc_config {
     uint32_t n_channels;   /* 512 */
     uint32_t n_mux;        /* 4 */
     uint32_t n_time_bins;  /* 48 */
-    uint32_t bin_seconds;  /* 3600 */
+    uint32_t bin_seconds;  /* 3600: ticks per time bin.  Times are integer ticks; a tick is one second for Fast5 input
+                              (the reference truncates to whole seconds with mktime, lib/fast5_reader.py:66-67) and may
+                              be finer (e.g. 1 us, bin_seconds = 3 600 000 000) for sequencing_summary.txt input whose
+                              start times are fractional (lib/seq_routines.py:845-846) */
     uint32_t time_mode;    /* 0: bin = floor((t - ref + tz) / bin_seconds)
-                              1: reference quirk, lib/fast5_reader.py:117-126: hour of day of (t - ref + tz),
+                              1: reference quirk, lib/fast5_reader.py:117-126: bin = that value mod 24 ("hour of day"),
                                  then per channel in start-time order every read from the first descent at
-                                 index >= 2 onwards gets +24 (needs bin_seconds == 3600) */
-    int32_t tz_offset_s;   /* local-zone offset the reference picks up through time.localtime (:118); 0 = UTC */
-    uint32_t reserved0;
-    int64_t ref_time_s;    /* RefTime / RefStart (lib/seq_routines.py:819-828, multi_read_fast5_reader.py:137) */
+                                 index >= 2 onwards gets +24; start times must span < 2^40 ticks */
+    int64_t tz_offset_s;   /* local-zone offset (ticks) the reference picks up through time.localtime (:118); 0 = UTC */
+    int64_t ref_time_s;    /* RefTime / RefStart in ticks (lib/seq_routines.py:819-828, multi_read_fast5_reader.py:137) */
     double fail_q;         /* 7.0 */
     uint64_t max_reads_hint; /* per-read arrays are pre-sized to this (0 = grow on demand) */
 } ppqc_config;
@@ -97,6 +99,20 @@ typedef struct ppqc_batch {
                                      (lib/fast5_reader.py:37-40,52) */
 } ppqc_batch;
 
+/* Reads whose statistics were computed elsewhere: the rows of albacore's sequencing_summary.txt, from which
+ * summary_reader (lib/seq_routines.py:831-863) builds ChannelDict without touching the sequences.  Host pointers.
+ * fail = mean_q < fail_q in fp64 (:855); quality bin = floor(mean_q - 6).  mux is 1 for every read when the caller
+ * wants the mux-less tables of that mode (configure n_mux = 1). */
+typedef struct ppqc_records {
+    uint64_t n_reads;
+    const uint32_t* length;       /* sequence_length_template column */
+    const double* mean_q;         /* mean_qscore_template column */
+    const uint32_t* gc_count;     /* optional (may be NULL = 0) */
+    const uint32_t* channel;
+    const uint8_t* mux;
+    const int64_t* start_time_s;  /* ticks */
+} ppqc_records;
+
 /* Per-read results, caller-allocated SoA; any pointer may be NULL to skip that column. */
 typedef struct ppqc_per_read {
     uint32_t* length;   /* offsets[i+1]-offsets[i]  (== sequence_length attr, lib/fast5_reader.py:55); 0 if flagged */
@@ -107,7 +123,7 @@ typedef struct ppqc_per_read {
                            (ONT mean_qscore, the attribute read at lib/fast5_reader.py:56) */
     uint64_t* err_hi;   /* S = err_hi * 2^32 + err_lo exactly; the halves are sums, not a canonical split */
     uint64_t* err_lo;
-    uint8_t* flags;     /* bit0: fail (mean_q < fail_q), bit1: fail_flag was set */
+    uint8_t* flags;     /* bit0: fail (mean_q < fail_q), bit1: fail_flag was set, bit2: submitted as a record */
 } ppqc_per_read;
 
 /* Run-level tables, caller-allocated (all uint64_t unless noted; NULL skips a table).
@@ -178,6 +194,8 @@ int ppqc_free_pinned(void* p);
 int ppqc_submit(ppqc_ctx* ctx, const ppqc_batch* host_batch, int slot);
 /* Same, for a batch already resident in HBM (kernel-only path). */
 int ppqc_submit_device(ppqc_ctx* ctx, const ppqc_batch* device_batch);
+/* Replaces the per-row work of summary_reader (lib/seq_routines.py:838-842, :852-855): appends pre-computed reads. */
+int ppqc_submit_records(ppqc_ctx* ctx, const ppqc_records* host_records);
 int ppqc_sync(ppqc_ctx* ctx);
 
 int ppqc_n_reads(ppqc_ctx* ctx, uint64_t* n);
@@ -209,6 +227,21 @@ int ppqc_sort_u32_device(ppqc_ctx* ctx, uint32_t* device_keys, uint64_t n);
 /* Counter-based synthetic read generator: fills device bases/quals for stream bytes [first, first+n). */
 int ppqc_synth_fill_device(ppqc_ctx* ctx, uint8_t* device_bases, uint8_t* device_quals, uint64_t first,
                            uint64_t n, uint64_t seed);
+
+/* Host-side FASTQ -> CSR packer (no GPU involved).  Replaces the record parsing the reference delegates to
+ * Biopython: SeqIO.parse(handle, "fastq") at lib/seq_routines.py:50 and SeqIO.read(StringIO(..), "fastq") at
+ * lib/fastqparser.py:12; bases = line 2 (lib/fast5_reader.py:57), quals = line 4.
+ * ppqc_fastq_scan counts the complete 4-line records in text[0, n) (final != 0: the block ends the file, so a last
+ * line without '\n' is complete) and reports how many bytes they span; malformed records fail with PPQC_E_INVALID
+ * where SeqIO raises ValueError.  ppqc_fastq_pack then copies sequences and qualities into caller buffers (n_bases
+ * bytes each), fills offsets[1..n_records] continuing from the caller-set offsets[0], and optionally the header span,
+ * the albacore header fields ch= and start_time= (ISO 8601, UTC seconds; INT64_MIN if absent) and the number of
+ * quality bytes outside '!'..'~'. */
+int ppqc_fastq_scan(const uint8_t* text, uint64_t n, int final, uint64_t* n_records, uint64_t* n_bases,
+                    uint64_t* consumed);
+int ppqc_fastq_pack(const uint8_t* text, uint64_t n, uint64_t n_records, uint8_t* bases, uint8_t* quals,
+                    uint64_t* offsets, uint64_t* header_off, uint32_t* header_len, uint32_t* channel,
+                    int64_t* start_time_s, uint64_t* n_bad_qual);
 
 #ifdef __cplusplus
 }

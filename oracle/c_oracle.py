@@ -17,7 +17,7 @@ def build():
 
 class _Cfg(C.Structure):
     _fields_ = [("n_channels", C.c_uint32), ("n_mux", C.c_uint32), ("n_time_bins", C.c_uint32),
-                ("bin_seconds", C.c_uint32), ("time_mode", C.c_uint32), ("tz_offset_s", C.c_int32),
+                ("bin_seconds", C.c_uint32), ("time_mode", C.c_uint32), ("tz_offset_s", C.c_int64),
                 ("ref_time_s", C.c_int64), ("fail_q", C.c_double)]
 
 
@@ -82,6 +82,10 @@ def tables(stats, channel, mux, start_time_s, fail_flag=None, cfg=None):
     else:
         eh = np.array([int(e) >> 64 for e in stats["err"]], dtype=np.uint64)
         el = np.array([int(e) & ((1 << 64) - 1) for e in stats["err"]], dtype=np.uint64)
+    rec = mq = None
+    if "is_record" in stats:
+        rec = np.ascontiguousarray(stats["is_record"], dtype=np.uint8)
+        mq = np.ascontiguousarray(stats["mean_q"], dtype=np.float64)
     z = lambda *s: np.zeros(s, dtype=np.int64)
     out = dict(totals=z(po.N_TOTALS), len_hist_log2=z(po.N_LEN_LOG2), len_hist_lin=z(po.N_LEN_LIN),
                q_hist=z(po.N_QHIST), gc_hist=z(po.N_GCHIST), hour_reads=z(nb), hour_bases=z(nb),
@@ -93,6 +97,7 @@ def tables(stats, channel, mux, start_time_s, fail_flag=None, cfg=None):
                      _p(np.ascontiguousarray(stats["qsum"], np.int64)), _p(np.ascontiguousarray(eh)),
                      _p(np.ascontiguousarray(el)), _p(channel), _p(mux), _p(t),
                      _p(ff) if ff is not None else None,
+                     _p(rec) if rec is not None else None, _p(mq) if mq is not None else None,
                      _p(out["totals"]), _p(out["len_hist_log2"]), _p(out["len_hist_lin"]), _p(out["q_hist"]),
                      _p(out["gc_hist"]), _p(out["hour_reads"]), _p(out["hour_bases"]), _p(out["chan_reads"]),
                      _p(out["chan_bases"]), _p(out["chan_fail"]), _p(out["cmh_reads"]), _p(out["cmh_bases"]),

@@ -137,7 +137,7 @@ uint64_t orc_n50(const uint32_t *lens, uint64_t n) {
 /* ---- run-level tables ----------------------------------------------------------------------- */
 typedef struct {
     uint32_t n_channels, n_mux, n_time_bins, bin_seconds, time_mode;
-    int32_t tz_offset_s;
+    int64_t tz_offset_s;
     int64_t ref_time_s;
     double fail_q;
 } orc_config;
@@ -162,6 +162,7 @@ static int64_t floordiv(int64_t a, int64_t b) { int64_t q = a / b; return (a % b
 void orc_tables(const orc_config *cfg, uint64_t R, const uint32_t *len_in, const uint32_t *gc_in, const uint32_t *n_in,
                 const int64_t *qsum_in, const uint64_t *err_hi, const uint64_t *err_lo, const uint32_t *channel,
                 const uint8_t *mux, const int64_t *start_time, const uint8_t *fail_flag,
+                const uint8_t *is_record, const double *mean_q,
                 int64_t *totals, int64_t *len_log2, int64_t *len_lin, int64_t *q_hist, int64_t *gc_hist,
                 int64_t *hour_reads, int64_t *hour_bases, int64_t *chan_reads, int64_t *chan_bases, int64_t *chan_fail,
                 int64_t *cmh_reads, int64_t *cmh_bases, int64_t *chan_min, int64_t *chan_max,
@@ -184,7 +185,7 @@ void orc_tables(const orc_config *cfg, uint64_t R, const uint32_t *len_in, const
         int flagged = fail_flag && fail_flag[i];
         len[i] = flagged ? 0 : len_in[i];
         int64_t sec = start_time[i] - cfg->ref_time_s + cfg->tz_offset_s;
-        if (cfg->time_mode == 1) { int64_t h = floordiv(sec, 3600) % 24; hour[i] = h < 0 ? h + 24 : h; }
+        if (cfg->time_mode == 1) { int64_t h = floordiv(sec, cfg->bin_seconds) % 24; hour[i] = h < 0 ? h + 24 : h; }
         else hour[i] = floordiv(sec, cfg->bin_seconds);
     }
     if (cfg->time_mode == 1 && R) {
@@ -220,6 +221,11 @@ void orc_tables(const orc_config *cfg, uint64_t R, const uint32_t *len_in, const
         u128 S = ((u128)err_hi[i] << 64) | err_lo[i];
         int fail, qbin = -1;
         if (flagged) { fail = 6.99 < cfg->fail_q; qbin = 0; }
+        else if (is_record && is_record[i]) {   /* sequencing_summary.txt row: float rule, lib/seq_routines.py:855 */
+            double q = mean_q[i];
+            fail = q < cfg->fail_q;
+            if (q >= 6.0 && q < 14.0) qbin = (int)floor(q - 6.0);
+        }
         else if (L == 0) fail = 0.0 < cfg->fail_q;
         else {
             fail = S > (u128)L * thr_fail;

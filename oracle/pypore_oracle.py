@@ -360,23 +360,59 @@ def summary_reader(lines, n_channels=512, tz_offset_s=0):
 # ----------------------------------------------------------------------------------------------
 
 
-def parse_fastq_records(text: bytes):
-    """Minimal 4-line FASTQ tokenizer (the record format of fastqparser.py:7-16 / row 8a-9):
-    yields (header, bases, quals).  Raises ValueError where SeqIO 'fastq' would."""
-    lines = text.split(b"\n")
+def parse_fastq_records(text: bytes, check_quality=True):
+    """FASTQ tokenizer with the semantics of ``SeqIO.parse(handle, 'fastq')`` (seq_routines.py:50,
+    fastqparser.py:12).  The parser is third-party (Biopython, unpinned in setup.py:9, <= 1.76 for
+    Python 2.7; not under /root/reference); this restates its published record grammar
+    (Bio.SeqIO.QualityIO.FastqGeneralIterator + the Sanger quality check of FastqPhredIterator):
+
+      * a record starts with an '@' line (title = rest, right-stripped);
+      * sequence lines follow until a line starting with '+' (an optional repeated title must
+        match); space or tab inside the sequence is an error;
+      * quality lines follow until the quality is at least as long as the sequence AND the next
+        line starts with '@' (or the file ends); blank lines there add nothing;
+      * lengths must match; with ``check_quality`` every quality byte must be '!'..'~'.
+    Lines are read in universal-newline mode ("rU", seq_routines.py:49).  Yields
+    (title, bases, quals); raises ValueError where SeqIO would."""
+    lines = text.replace(b"\r\n", b"\n").replace(b"\r", b"\n").split(b"\n")
     if lines and lines[-1] == b"":
-        lines.pop()
-    if len(lines) % 4:
-        raise ValueError("truncated FASTQ")
-    for i in range(0, len(lines), 4):
-        h, s, p, q = lines[i:i + 4]
-        if not h.startswith(b"@") or not p.startswith(b"+"):
-            raise ValueError("bad FASTQ record")
-        if len(s) != len(q):
-            raise ValueError("sequence/quality length mismatch")
-        if any(c < 33 or c > 126 for c in q):
-            raise ValueError("invalid quality character")
-        yield h[1:], s, q
+        lines.pop()          # the text after the final newline is not a line
+    i, n = 0, len(lines)
+    if n == 0:
+        return
+    while i < n:
+        line = lines[i]; i += 1
+        if not line.startswith(b"@"):
+            raise ValueError("Records in Fastq files should start with '@' character")
+        title = line[1:].rstrip()
+        seq = lines[i].rstrip() if i < n else b""
+        i += 1
+        while True:
+            if i >= n:
+                raise ValueError("End of file without quality information.")
+            line = lines[i]; i += 1
+            if line.startswith(b"+"):
+                second = line[1:].rstrip()
+                if second and second != title:
+                    raise ValueError("Sequence and quality captions differ.")
+                break
+            seq += line.rstrip()
+        if b" " in seq or b"\t" in seq:
+            raise ValueError("Whitespace is not allowed in the sequence.")
+        qual = lines[i].rstrip() if i < n else b""
+        i += 1
+        while i < n:
+            line = lines[i]
+            if line.startswith(b"@") and len(qual) >= len(seq):
+                break
+            qual += line.rstrip()
+            i += 1
+        if len(seq) != len(qual):
+            raise ValueError("Lengths of sequence and quality values differs for %r (%i and %i)."
+                             % (title, len(seq), len(qual)))
+        if check_quality and any(c < 33 or c > 126 for c in qual):
+            raise ValueError("Invalid character in quality string")
+        yield title, seq, qual
 
 
 def fastq_reader(text: bytes):
@@ -560,10 +596,18 @@ def build_tables(stats, channel, mux, start_time_s, fail_flag=None, cfg=None):
     thr = [q_threshold(cfg["fail_q"])] + [q_threshold(6.0 + j) for j in range(N_QHIST + 1)]
     fail = np.zeros(R, dtype=bool)
     qbin = np.full(R, -1, dtype=np.int64)
+    is_record = np.asarray(stats["is_record"]).astype(bool) if "is_record" in stats else np.zeros(R, bool)
     for i in range(R):
         if flagged[i]:
             fail[i] = 6.99 < cfg["fail_q"]      # default QScore of a 'fail' path, fast5_reader.py:37
             qbin[i] = 0                          # floor(6.99 - 6)
+            continue
+        if is_record[i]:
+            # rows of sequencing_summary.txt: only the float exists (seq_routines.py:852-855)
+            q = float(stats["mean_q"][i])
+            fail[i] = q < cfg["fail_q"]
+            if 6.0 <= q < 14.0:
+                qbin[i] = int(math.floor(q - 6.0))
             continue
         L, S = int(length[i]), int(err[i])
         if L == 0:
@@ -581,7 +625,7 @@ def build_tables(stats, channel, mux, start_time_s, fail_flag=None, cfg=None):
     sec = t - cfg["ref_time_s"] + cfg["tz_offset_s"]
     hour = np.floor_divide(sec, cfg["bin_seconds"])
     if cfg["time_mode"] == 1:
-        hour = np.mod(np.floor_divide(sec, 3600), 24)
+        hour = np.mod(np.floor_divide(sec, cfg["bin_seconds"]), 24)
         for c in np.unique(channel[good_ch]):
             idx = np.nonzero(channel == c)[0]
             idx = idx[np.argsort(t[idx], kind="stable")]

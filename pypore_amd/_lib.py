@@ -24,10 +24,10 @@ TOTALS = ("n_reads", "n_bases", "n_fail", "n_gc", "n_n", "qsum", "n_binned", "ba
 # every symbol include/pypore_qc.h declares (tests check that the built library exports all of them)
 SYMBOLS = (
     "ppqc_last_error", "ppqc_abi_version", "ppqc_device_count", "ppqc_config_default", "ppqc_create",
-    "ppqc_destroy", "ppqc_reset", "ppqc_alloc_pinned", "ppqc_free_pinned", "ppqc_submit", "ppqc_submit_device",
+    "ppqc_destroy", "ppqc_reset", "ppqc_alloc_pinned", "ppqc_free_pinned", "ppqc_submit", "ppqc_submit_device", "ppqc_submit_records",
     "ppqc_sync", "ppqc_n_reads", "ppqc_read_stats", "ppqc_read_hours", "ppqc_finalize_extremes",
     "ppqc_finalize_tables", "ppqc_finalize_n50", "ppqc_fetch_tables", "ppqc_finalize", "ppqc_device_tables_view",
-    "ppqc_timings", "ppqc_reset_timings", "ppqc_sort_u32_device", "ppqc_synth_fill_device",
+    "ppqc_timings", "ppqc_reset_timings", "ppqc_sort_u32_device", "ppqc_synth_fill_device", "ppqc_fastq_scan", "ppqc_fastq_pack",
 )
 
 
@@ -40,7 +40,7 @@ class PPQCError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_channels", C.c_uint32), ("n_mux", C.c_uint32),
                 ("n_time_bins", C.c_uint32), ("bin_seconds", C.c_uint32), ("time_mode", C.c_uint32),
-                ("tz_offset_s", C.c_int32), ("reserved0", C.c_uint32), ("ref_time_s", C.c_int64),
+                ("tz_offset_s", C.c_int64), ("ref_time_s", C.c_int64),
                 ("fail_q", C.c_double), ("max_reads_hint", C.c_uint64)]
 
 
@@ -48,6 +48,11 @@ class Batch(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_bytes", C.c_uint64), ("bases", C.c_void_p), ("quals", C.c_void_p),
                 ("offsets", C.c_void_p), ("channel", C.c_void_p), ("mux", C.c_void_p), ("start_time_s", C.c_void_p),
                 ("fail_flag", C.c_void_p)]
+
+
+class Records(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("length", C.c_void_p), ("mean_q", C.c_void_p), ("gc_count", C.c_void_p),
+                ("channel", C.c_void_p), ("mux", C.c_void_p), ("start_time_s", C.c_void_p)]
 
 
 class PerRead(C.Structure):
@@ -116,6 +121,7 @@ def load():
         "ppqc_destroy": [P], "ppqc_reset": [P],
         "ppqc_alloc_pinned": [C.POINTER(P), C.c_size_t], "ppqc_free_pinned": [P],
         "ppqc_submit": [P, C.POINTER(Batch), C.c_int], "ppqc_submit_device": [P, C.POINTER(Batch)],
+        "ppqc_submit_records": [P, C.POINTER(Records)],
         "ppqc_sync": [P], "ppqc_n_reads": [P, C.POINTER(C.c_uint64)],
         "ppqc_read_stats": [P, C.POINTER(PerRead), C.c_uint64, C.c_uint64],
         "ppqc_read_hours": [P, P, C.c_uint64, C.c_uint64],
@@ -125,6 +131,8 @@ def load():
         "ppqc_timings": [P, C.POINTER(Timing)], "ppqc_reset_timings": [P],
         "ppqc_sort_u32_device": [P, P, C.c_uint64],
         "ppqc_synth_fill_device": [P, P, P, C.c_uint64, C.c_uint64, C.c_uint64],
+        "ppqc_fastq_scan": [P, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+        "ppqc_fastq_pack": [P, C.c_uint64, C.c_uint64, P, P, P, P, P, P, P, C.POINTER(C.c_uint64)],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)

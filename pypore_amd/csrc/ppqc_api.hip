@@ -16,6 +16,7 @@ static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+int ppqc_set_error(int code, const std::string& msg) { return fail(code, msg); }   // for the other host units
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
@@ -215,8 +216,6 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     if (cfg->n_channels == 0 || cfg->n_channels > (1u << 20) || cfg->n_mux == 0 || cfg->n_mux > 255 ||
         cfg->n_time_bins == 0 || cfg->n_time_bins > 4096 || cfg->bin_seconds == 0 || cfg->time_mode > 1)
         return fail(PPQC_E_INVALID, "config out of range");
-    if (cfg->time_mode == 1 && cfg->bin_seconds != 3600)
-        return fail(PPQC_E_INVALID, "time_mode 1 (reference hour-of-day quirk) needs bin_seconds == 3600");
     if (!(cfg->fail_q >= 0.0 && cfg->fail_q <= 93.0)) return fail(PPQC_E_INVALID, "fail_q out of range");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -415,6 +414,37 @@ int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
     return PPQC_OK;
 }
 
+int ppqc_submit_records(ppqc_ctx* c, const ppqc_records* r) {
+    if (!c || !r) return fail(PPQC_E_INVALID, "null argument");
+    const uint64_t n = r->n_reads;
+    if (n == 0) return PPQC_OK;
+    if (n >= (1ull << 32)) return fail(PPQC_E_RANGE, "more than 2^32-1 records");
+    if (!r->length || !r->mean_q || !r->channel || !r->mux || !r->start_time_s)
+        return fail(PPQC_E_INVALID, "null record column");
+    HIPCHK(hipSetDevice(c->device));
+    CHK(ensure_reads(c, c->n_reads + n));
+    // stage the columns in one device buffer (freed after the kernel; this path is I/O bound on the text table)
+    const uint64_t o_len = 0, o_q = o_len + n * 4 + 8, o_q8 = (o_q + 7) & ~7ull, o_gc = o_q8 + n * 8,
+                   o_ch = o_gc + n * 4, o_t = ((o_ch + n * 4) + 7) & ~7ull, o_mux = o_t + n * 8, total = o_mux + n + 64;
+    uint8_t* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, total));
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(d + o_len, r->length, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d + o_q8, r->mean_q, n * 8, hipMemcpyHostToDevice, s));
+    if (r->gc_count) HIPCHK(hipMemcpyAsync(d + o_gc, r->gc_count, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d + o_ch, r->channel, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d + o_t, r->start_time_s, n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d + o_mux, r->mux, n, hipMemcpyHostToDevice, s));
+    HIPCHK(launch_records(c->ra, c->n_reads, n, (const uint32_t*)(d + o_len), (const double*)(d + o_q8),
+                          r->gc_count ? (const uint32_t*)(d + o_gc) : nullptr, (const uint32_t*)(d + o_ch),
+                          d + o_mux, (const int64_t*)(d + o_t), c->tp.fail_q, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(d));
+    c->n_reads += n;
+    c->state = 0;
+    return PPQC_OK;
+}
+
 static int resolve_timings(ppqc_ctx* c) {
     for (auto& p : c->pending) {
         float ms = 0.f;
@@ -498,11 +528,11 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
         uint64_t span = 0;
         if (tmm[0] <= tmm[1]) {
             span = (uint64_t)tmm[1] - (uint64_t)tmm[0];
-            if (span >= (1ull << 32)) return fail(PPQC_E_RANGE, "time_mode 1: start times span more than 2^32 s");
+            if (span >= (1ull << 40)) return fail(PPQC_E_RANGE, "time_mode 1: start times span 2^40 ticks or more");
         }
         CHK(ensure_sort64(c, n));
         HIPCHK(launch_mode1_keys(c->ra, n, c->tp, c->tminmax, c->sk64, c->vals, s));
-        const uint32_t mask = (bytes_mask_for(span) & 0xFu) | ((bytes_mask_for((uint64_t)c->cfg.n_channels + 1) & 0xFu) << 4);
+        const uint32_t mask = (bytes_mask_for(span) & 0x1Fu) | ((bytes_mask_for((uint64_t)c->cfg.n_channels + 1) & 0x7u) << 5);
         HIPCHK(sort_u64_pairs(c->sk64, c->sk64_tmp, c->vals, c->vals_tmp, n, c->counts, mask, s));
         HIPCHK(launch_mode1_hours(c->ra, n, c->tp, c->sk64, c->vals, c->chan_start, c->first_desc, s));
     }

@@ -66,7 +66,7 @@ struct TableLayout {
 struct TableParams {
     TableLayout lay;
     uint32_t bin_seconds, time_mode;
-    int32_t tz_offset_s;
+    int64_t tz_offset_s;
     int64_t ref_time_s;
     uint64_t thr_fail;         // fixed-point image of fail_q
     uint64_t thr_q[PPQC_N_QHIST + 1];   // images of 6,7,...,14
@@ -78,6 +78,11 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
                               Partial* head, Partial* tail, int n_cu, hipStream_t s);
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint64_t thr_fail, double fail_q, hipStream_t s);
+
+// Pre-computed reads (sequencing_summary.txt rows): device arrays of n entries appended at read_base.
+hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const uint32_t* len, const double* mean_q,
+                          const uint32_t* gc, const uint32_t* channel, const uint8_t* mux, const int64_t* time,
+                          double fail_q, hipStream_t s);
 
 hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* max_buf, uint64_t* min_buf,
                            int64_t* tminmax, hipStream_t s);

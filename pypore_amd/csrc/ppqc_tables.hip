@@ -14,7 +14,7 @@ __device__ __forceinline__ int64_t floordiv64(int64_t a, int64_t b) {
 }
 // hour of day of (t - ref + tz): int(time.strftime('%H', time.localtime(t - ref)))  (lib/fast5_reader.py:118)
 __device__ __forceinline__ int32_t hour_of_day(int64_t t, const TableParams& tp) {
-    int64_t h = floordiv64(t - tp.ref_time_s + tp.tz_offset_s, 3600) % 24;
+    int64_t h = floordiv64(t - tp.ref_time_s + tp.tz_offset_s, (int64_t)tp.bin_seconds) % 24;
     return (int32_t)(h < 0 ? h + 24 : h);
 }
 
@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256) void tables_kernel(ReadArrays ra, uint64_t n, 
         // quality histogram: bin j <=> 6+j <= mean_q < 7+j <=> L*e(7+j) < S <= L*e(6+j)  (exact integers)
         int qbin = -1;
         if (fl & 2u) qbin = 0;   // flagged read: QScore 6.99
-        else if (L != 0) {
+        else if (fl & 4u) {      // pre-computed record: the reference only has the float, floor(q - 6) in fp64
+            const double q = ra.mean_q[i];
+            if (q >= 6.0 && q < 14.0) qbin = (int)floor(q - 6.0);
+        } else if (L != 0) {
             const unsigned __int128 S = ((unsigned __int128)ra.err_hi[i] << 32) + ra.err_lo[i];
 #pragma unroll
             for (int j = 0; j < PPQC_N_QHIST; ++j)
@@ -193,8 +196,8 @@ __global__ __launch_bounds__(256) void mode1_keys_kernel(ReadArrays ra, uint64_t
     const uint32_t ch = ra.channel[i];
     const bool good = ch >= 1 && ch <= tp.lay.n_channels;
     // reads with a bad channel sort behind every real channel (sentinel channel n_channels + 1) and are skipped later
-    keys[i] = good ? (((uint64_t)ch << 32) | (uint64_t)(uint32_t)(ra.time[i] - tminmax[0]))
-                   : ((uint64_t)(tp.lay.n_channels + 1) << 32);
+    keys[i] = good ? (((uint64_t)ch << 40) | ((uint64_t)(ra.time[i] - tminmax[0]) & 0xFFFFFFFFFFull))
+                   : ((uint64_t)(tp.lay.n_channels + 1) << 40);
     vals[i] = (uint32_t)i;
     ra.hour[i] = -1;
 }
@@ -203,9 +206,9 @@ __global__ __launch_bounds__(256) void mode1_starts_kernel(const uint64_t* keys,
                                                            uint32_t* chan_start) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const uint32_t ch = (uint32_t)(keys[p] >> 32);
+    const uint32_t ch = (uint32_t)(keys[p] >> 40);
     if (ch > nch) return;
-    if (p == 0 || (uint32_t)(keys[p - 1] >> 32) != ch) chan_start[ch - 1] = (uint32_t)p;
+    if (p == 0 || (uint32_t)(keys[p - 1] >> 40) != ch) chan_start[ch - 1] = (uint32_t)p;
 }
 
 __global__ __launch_bounds__(256) void mode1_descent_kernel(ReadArrays ra, uint64_t n, TableParams tp,
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256) void mode1_descent_kernel(ReadArrays ra, uint6
                                                             const uint32_t* chan_start, uint32_t* first_desc) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const uint32_t ch = (uint32_t)(keys[p] >> 32);
+    const uint32_t ch = (uint32_t)(keys[p] >> 40);
     if (ch > tp.lay.n_channels) return;
     const uint32_t pos = (uint32_t)p - chan_start[ch - 1];
     if (pos < 2) return;
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256) void mode1_assign_kernel(ReadArrays ra, uint64
                                                            const uint32_t* chan_start, const uint32_t* first_desc) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const uint32_t ch = (uint32_t)(keys[p] >> 32);
+    const uint32_t ch = (uint32_t)(keys[p] >> 40);
     if (ch > tp.lay.n_channels) return;
     const uint32_t pos = (uint32_t)p - chan_start[ch - 1];
     const uint32_t idx = vals[p];
@@ -241,6 +244,28 @@ __global__ void fill_u64_kernel(uint64_t* p, uint64_t n, uint64_t v) {
 hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+
+// Pre-computed reads: fill the per-read record arrays directly (no sequence bytes exist for them).
+__global__ __launch_bounds__(256) void records_kernel(ReadArrays ra, uint64_t base, uint64_t n, const uint32_t* len,
+                                                      const double* mean_q, const uint32_t* gc, const uint32_t* channel,
+                                                      const uint8_t* mux, const int64_t* time, double fail_q) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t g = base + i;
+    const double q = mean_q[i];
+    ra.len[g] = len[i]; ra.gc[g] = gc ? gc[i] : 0; ra.nn[g] = 0; ra.qsum[g] = 0; ra.mean_q[g] = q;
+    ra.err_hi[g] = 0; ra.err_lo[g] = 0;
+    ra.flags[g] = (uint8_t)(4u | (q < fail_q ? 1u : 0u));   // float(q) < 7.00, lib/seq_routines.py:855
+    ra.channel[g] = channel[i]; ra.mux[g] = mux[i]; ra.time[g] = time[i];
+}
+hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const uint32_t* len, const double* mean_q,
+                          const uint32_t* gc, const uint32_t* channel, const uint8_t* mux, const int64_t* time,
+                          double fail_q, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ra, read_base, n, len, mean_q,
+                       gc, channel, mux, time, fail_q);
     return hipGetLastError();
 }
 

@@ -91,6 +91,20 @@ class QCContext:
                     fail_flag_ptr)
         L.check(self._lib.ppqc_submit_device(self._ctx, C.byref(b)))
 
+    def submit_records(self, length, mean_q, channel, mux, start_time_s, gc_count=None):
+        """Reads whose statistics come from a table (albacore sequencing_summary.txt, lib/seq_routines.py:831-863)."""
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        mean_q = np.ascontiguousarray(mean_q, dtype=np.float64)
+        channel = np.ascontiguousarray(channel, dtype=np.uint32)
+        mux = np.ascontiguousarray(mux, dtype=np.uint8)
+        t = np.ascontiguousarray(start_time_s, dtype=np.int64)
+        gc = None if gc_count is None else np.ascontiguousarray(gc_count, dtype=np.uint32)
+        n = len(length)
+        if not (len(mean_q) == len(channel) == len(mux) == len(t) == n) or (gc is not None and len(gc) != n):
+            raise ValueError("record columns must have equal lengths")
+        r = L.Records(n, _ptr(length), _ptr(mean_q), _ptr(gc), _ptr(channel), _ptr(mux), _ptr(t))
+        L.check(self._lib.ppqc_submit_records(self._ctx, C.byref(r)))
+
     def sync(self):
         L.check(self._lib.ppqc_sync(self._ctx))
         self._keep.clear()

@@ -61,7 +61,7 @@ def test_config_default_and_validation(lib):
     bad.n_channels = 0
     assert lib.ppqc_create(C.byref(ctx), 0, C.byref(bad)) == -1 and b"config" in lib.ppqc_last_error()
     bad = _lib.Config.from_buffer_copy(cfg)
-    bad.time_mode, bad.bin_seconds = 1, 60
+    bad.time_mode = 2
     assert lib.ppqc_create(C.byref(ctx), 0, C.byref(bad)) == -1
     bad = _lib.Config.from_buffer_copy(cfg)
     bad.struct_size = 8

@@ -220,3 +220,113 @@ def test_device_batch_config4_adversarial_and_determinism(qc, c_oracle):
     for k in outs[0][0]:
         assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
     assert_tables_equal(outs[0][1], outs[1][1])
+
+
+def _record_columns(seed, n, n_channels, hours=47, tick=1):
+    rng = np.random.default_rng(seed)
+    length = rng.integers(0, 60000, n).astype(np.uint32)
+    mean_q = np.round(rng.normal(9.5, 2.5, n), 3)
+    mean_q[:8] = (7.0, 6.999, 6.0, 5.999, 13.999, 14.0, 0.0, 93.0)     # both sides of every threshold
+    gc = (length * rng.uniform(0.2, 0.7, n)).astype(np.uint32)
+    gc[rng.random(n) < 0.1] = 0
+    channel = rng.integers(1, n_channels + 1, n).astype(np.uint32)
+    channel[rng.random(n) < 0.01] = n_channels + 5
+    mux = np.ones(n, np.uint8)
+    t = (1_528_000_000 * tick + rng.integers(0, hours * 3600 * tick, n)).astype(np.int64)
+    return length, mean_q, gc, channel, mux, t
+
+
+def _record_stats(length, mean_q, gc):
+    n = len(length)
+    return dict(length=length, gc=gc, n=np.zeros(n, np.uint32), qsum=np.zeros(n, np.int64), err=[0] * n,
+                mean_q=mean_q, is_record=np.ones(n, np.uint8))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_records_path_sequencing_summary_rows(qc, c_oracle, mode):
+    """ppqc_submit_records: rows of sequencing_summary.txt (lib/seq_routines.py:831-863), mux-less tables, the float
+    fail rule of :855."""
+    from oracle import pypore_oracle as po
+    cfg = dict(BASE_CFG, n_mux=1, time_mode=mode, n_channels=64, tz_offset_s=7200)
+    length, mean_q, gc, channel, mux, t = _record_columns(61 + mode, 4000, 64)
+    with qc.QCContext(device=0, **cfg) as ctx:
+        for a, e in ((0, 1500), (1500, 1500), (1500, 4000)):      # appended in pieces, one of them empty
+            ctx.submit_records(length[a:e], mean_q[a:e], channel[a:e], mux[a:e], t[a:e], gc[a:e])
+        got = ctx.read_stats()
+        tables = ctx.finalize()
+    assert np.array_equal(got["length"], length) and np.array_equal(got["gc"], gc)
+    assert np.array_equal(got["mean_q"], mean_q)
+    assert np.array_equal(got["flags"], (4 | (mean_q < 7.0)).astype(np.uint8))
+    stats = _record_stats(length, mean_q, gc)
+    wt = c_oracle.tables(stats, channel, mux, t, None, cfg)
+    assert_tables_equal(tables, wt, "records mode %d" % mode)
+    small = slice(0, 600)
+    with qc.QCContext(device=0, **cfg) as ctx:
+        ctx.submit_records(length[small], mean_q[small], channel[small], mux[small], t[small], gc[small])
+        ts = ctx.finalize()
+    assert_tables_equal(ts, po.build_tables(_record_stats(length[small], mean_q[small], gc[small]), channel[small],
+                                            mux[small], t[small], None, cfg), "records vs python oracle")
+
+
+def test_records_and_csr_batches_mix_in_one_run(qc, c_oracle):
+    b = random_batch(71, 1200, 400)
+    length, mean_q, gc, channel, mux, t = _record_columns(72, 900, 512, hours=48)
+    with qc.QCContext(device=0, **BASE_CFG) as ctx:
+        ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], b["fail_flag"])
+        ctx.submit_records(length, mean_q, channel, mux, t, gc)
+        tables = ctx.finalize()
+    w = c_oracle.per_read(b["bases"], b["quals"], b["offsets"], nthreads=2)
+    nb = len(b["channel"])
+    stats = dict(length=np.concatenate([w["length"], length]), gc=np.concatenate([w["gc"], gc]),
+                 n=np.concatenate([w["n"], np.zeros(len(length), np.uint32)]),
+                 qsum=np.concatenate([w["qsum"], np.zeros(len(length), np.int64)]),
+                 err=list(w["err"]) + [0] * len(length), mean_q=np.concatenate([w["mean_q"], mean_q]),
+                 is_record=np.concatenate([np.zeros(nb, np.uint8), np.ones(len(length), np.uint8)]))
+    ff = np.concatenate([b["fail_flag"], np.zeros(len(length), np.uint8)])
+    wt = c_oracle.tables(stats, np.concatenate([b["channel"], channel]), np.concatenate([b["mux"], mux]),
+                         np.concatenate([b["time"], t]), ff, BASE_CFG)
+    assert_tables_equal(tables, wt, "mixed")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sub_second_ticks(qc, c_oracle, mode):
+    """Times in milliseconds: bin_seconds = 3 600 000 ticks, 64-bit tz offset and reference time."""
+    tick = 1000
+    cfg = dict(BASE_CFG, n_mux=1, time_mode=mode, n_channels=16, bin_seconds=3600 * tick, tz_offset_s=3600 * tick,
+               ref_time_s=1_528_000_000 * tick)
+    length, mean_q, gc, channel, mux, t = _record_columns(81, 3000, 16, hours=47, tick=tick)
+    with qc.QCContext(device=0, **cfg) as ctx:
+        ctx.submit_records(length, mean_q, channel, mux, t, gc)
+        tables = ctx.finalize()
+    assert_tables_equal(tables, c_oracle.tables(_record_stats(length, mean_q, gc), channel, mux, t, None, cfg))
+
+
+def test_fastq_text_to_tables(qc, c_oracle):
+    """FASTQ text -> ppqc_fastq_pack -> CSR -> GPU: per-record GC of fastq_reader (lib/seq_routines.py:40-53) and the
+    header-derived channel / start time."""
+    from oracle import pypore_oracle as po
+    from pypore_amd import fastq_io
+    rng = np.random.default_rng(91)
+    recs = []
+    for i in range(400):
+        L = int(rng.integers(0, 3000))
+        s = bytes(rng.choice(np.frombuffer(b"ACGTNacgtSs", np.uint8), L))
+        q = bytes(rng.integers(33, 80, L, dtype=np.uint8))
+        sec = int(rng.integers(0, 47 * 3600))
+        hdr = "r%d runid=x read=%d ch=%d start_time=2018-06-03T%02d:%02d:%02dZ" % (
+            i, i, 1 + i % 512, (sec // 3600) % 24, (sec // 60) % 60, sec % 60)
+        recs.append((hdr.encode(), s, q))
+    text = b"".join(b"@" + h + b"\n" + s + b"\n+\n" + q + b"\n" for h, s, q in recs)
+    p = fastq_io.pack_fastq(text)
+    ref = int(p["start_time"].min())
+    cfg = dict(BASE_CFG, ref_time_s=ref)
+    mux = np.ones(p["n_reads"], np.uint8)
+    with qc.QCContext(device=0, **cfg) as ctx:
+        ctx.submit(p["bases"], p["quals"], p["offsets"], p["channel"], mux, p["start_time"])
+        got = ctx.read_stats()
+        tables = ctx.finalize()
+    gc_pct = [g * 100.0 / l if l else 0.0 for g, l in zip(got["gc"].tolist(), got["length"].tolist())]
+    assert gc_pct == po.fastq_reader(text)
+    want = c_oracle.per_read(p["bases"], p["quals"], p["offsets"], nthreads=2)
+    _check_reads(got, want)
+    assert_tables_equal(tables, c_oracle.tables(want, p["channel"], mux, p["start_time"], None, cfg))
