@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--time-bins", type=int, default=48)
     ap.add_argument("--seed", type=int, default=20240601)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-gbases", type=float, default=0.0, help="0 = auto (about 10-20 s of CPU work)")
+    ap.add_argument("--cpu-sample-gbases", type=float, default=0.0, help="0 = auto (2 Gbases prefix)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work timed for the cpu_baseline leg")
     ap.add_argument("--workload", default="config2", choices=["config2", "config4", "config4adv"])
     return ap.parse_args()
 
@@ -149,6 +150,7 @@ def main():
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": None, "kernel_ms": round(k_ms, 4), "bytes_per_launch": int(alg_bytes)},
         }
+        out["roofline"].update(pmc_traffic(int(alg_bytes)))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, off, d_bases, d_quals, ctx)
         print(json.dumps(out), flush=True)
@@ -157,27 +159,47 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(alg_bytes):
+    """HBM bytes per tile-kernel launch from the committed rocprofv3 PMC passes of this same command (profiles/;
+    2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be collected from
+    inside the timed process, so the newest profile whose algorithmic byte count equals this run's is quoted."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True):
+        try:
+            t = json.load(open(f)).get("tile_kernel_traffic_bytes_per_launch") or {}
+        except (OSError, ValueError):
+            continue
+        if t.get("algorithmic") == alg_bytes and t.get("total"):
+            return {"traffic": int(t["total"]), "traffic_source": "profiles/" + os.path.basename(f)}
+    return {}
+
+
 def cpu_baseline(a, off, d_bases, d_quals, ctx):
-    """The C oracle ("port" of the reference's per-read arithmetic) on the host cores, on a bounded prefix of
-    the same workload; also re-checks the GPU records of that prefix against it."""
+    """The C oracle ("port" of the reference's per-read arithmetic) on the host cores, on a bounded sample of the
+    same workload: a prefix of at most 2 Gbases, passed over repeatedly until about 12 s of CPU work have been
+    timed.  Also re-checks the GPU records of that prefix against it."""
     from oracle import c_oracle as co
     cores = min(16, os.cpu_count() or 1)
-    target = a.cpu_sample_gbases * 1e9 if a.cpu_sample_gbases > 0 else 0.35e9 * cores   # ~10-20 s at ~0.03 Gb/s/core..
+    target = a.cpu_sample_gbases * 1e9 if a.cpu_sample_gbases > 0 else 2.0e9
     r = int(np.searchsorted(off, np.uint64(target), side="right")) - 1
     r = max(1, min(r, len(off) - 1))
     nb = int(off[r])
     hb = d_bases[:nb].cpu().numpy()
     hq = d_quals[:nb].cpu().numpy()
     sub = off[: r + 1].copy()
-    t0 = time.perf_counter()
-    want = co.per_read(hb, hq, sub, nthreads=cores)
-    dt = time.perf_counter() - t0
+    want = co.per_read(hb, hq, sub, nthreads=cores)          # untimed first pass: page-in + the parity re-check
     got = ctx.read_stats(0, r)
     ok = all(np.array_equal(got[k], want[k]) for k in ("length", "gc", "n", "qsum"))
     ok = ok and [(int(h) << 32) + int(l) for h, l in zip(got["err_hi"], got["err_lo"])] == [int(e) for e in want["err"]]
-    return {"value": round(nb / dt / 1e9, 3), "unit": "Gbases/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads (%.2f Gbases) of the same workload, oracle/ppqc_oracle.c per-read statistics, "
-                      "%d pthreads, %.1f s" % (r, nb / 1e9, cores, dt),
+    passes, dt, budget = 0, 0.0, a.cpu_seconds
+    while dt < budget and passes < 1000:
+        t0 = time.perf_counter()
+        co.per_read(hb, hq, sub, nthreads=cores)
+        dt += time.perf_counter() - t0
+        passes += 1
+    return {"value": round(nb * passes / dt / 1e9, 3), "unit": "Gbases/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads (%.2f Gbases) of the same workload x %d passes, oracle/ppqc_oracle.c per-read "
+                      "statistics, %d pthreads, %.1f s timed" % (r, nb / 1e9, passes, cores, dt),
             "gpu_matches_cpu_on_sample": bool(ok)}
 
 
