@@ -40,7 +40,7 @@ class QCContext:
         self.cfg = cfg
         self._ctx = C.c_void_p()
         L.check(self._lib.ppqc_create(C.byref(self._ctx), int(device), C.byref(cfg)))
-        self._keep = []   # host arrays that must outlive an asynchronous submit
+        self._keep = {}   # per staging slot: host arrays that must outlive the asynchronous submit
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
@@ -81,8 +81,9 @@ class QCContext:
         if len(bases) < nbytes or len(quals) < nbytes:
             raise ValueError("bases/quals shorter than offsets[-1]")
         b = L.Batch(R, nbytes, _ptr(bases), _ptr(quals), _ptr(offsets), _ptr(channel), _ptr(mux), _ptr(t), _ptr(ff))
-        self._keep.append((bases, quals, offsets, channel, mux, t, ff))
+        # ppqc_submit waits for the slot's previous batch before reusing it, so only the newest batch per slot is held
         L.check(self._lib.ppqc_submit(self._ctx, C.byref(b), int(slot)))
+        self._keep[int(slot)] = (bases, quals, offsets, channel, mux, t, ff)
 
     def submit_device(self, n_reads, n_bytes, bases_ptr, quals_ptr, offsets_ptr, channel_ptr, mux_ptr, time_ptr,
                       fail_flag_ptr=None):
