@@ -208,6 +208,30 @@ class QCContext:
         L.check(self._lib.ppqc_synth_fill_device(self._ctx, bases_ptr, quals_ptr, int(first), int(n), int(seed)))
 
 
+class PinnedBuffer:
+    """Page-locked host memory from ``ppqc_alloc_pinned`` viewed as a numpy uint8 array: batches sliced out of it
+    are copied by DMA, asynchronously, in ``submit`` (the loaders' double buffer of BASELINE config 5)."""
+
+    def __init__(self, nbytes):
+        self._lib = L.load()
+        self._ptr = C.c_void_p()
+        L.check(self._lib.ppqc_alloc_pinned(C.byref(self._ptr), int(nbytes)))
+        self.nbytes = int(nbytes)
+        self.array = np.ctypeslib.as_array(C.cast(self._ptr, C.POINTER(C.c_uint8)), shape=(max(1, self.nbytes),))[:self.nbytes]
+
+    def close(self):
+        if getattr(self, "_ptr", None):
+            self.array = None
+            self._lib.ppqc_free_pinned(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def device_count():
     n = C.c_int()
     L.check(L.load().ppqc_device_count(C.byref(n)))
