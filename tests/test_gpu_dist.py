@@ -1,0 +1,46 @@
+"""The RCCL merge path of bench.py --gpus N, exercised on the one GPU a test box has: a 1-rank "nccl" group runs
+finalize_distributed (all-reduce MAX/MIN, all-reduce SUM on the fused table buffer, all-gather of the lengths, N50
+over the gathered lengths) directly on the library's device buffers.  The N-rank arithmetic is covered by the 2-rank
+gloo test (tests/test_dist_gloo.py)."""
+import socket
+
+import numpy as np
+import pytest
+
+from util import random_batch, assert_tables_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def test_finalize_distributed_one_rank_nccl_and_zero_copy_views(c_oracle):
+    import torch
+    import torch.distributed as dist
+    from pypore_amd import qc
+    from pypore_amd.merge import finalize_distributed
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        cfg = dict(n_channels=3000, n_mux=4, n_time_bins=72, bin_seconds=3600, time_mode=0, tz_offset_s=0,
+                   ref_time_s=1_528_000_000, fail_q=7.0)
+        b = random_batch(5, 20000, 300, n_channels=3000, hours=75)
+        with qc.QCContext(device=0, **cfg) as ctx:
+            ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], b["fail_flag"])
+            merged = finalize_distributed(ctx, dist, torch)
+            views, d = ctx.device_tables()
+            t_sum = torch.as_tensor(views["sum"], device="cuda")
+            assert t_sum.data_ptr() == d.sum_buf and t_sum.numel() == d.n_sum      # in-place collectives need zero copy
+            lens = torch.as_tensor(views["lengths"], device="cuda")
+            assert lens.data_ptr() == d.lengths and lens.numel() == len(b["channel"])
+            ctx.reset()
+            ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], b["fail_flag"])
+            single = ctx.finalize()
+        assert_tables_equal(merged, single, "1-rank merge")
+        want = c_oracle.per_read(b["bases"], b["quals"], b["offsets"], nthreads=4)
+        assert_tables_equal(merged, c_oracle.tables(want, b["channel"], b["mux"], b["time"], b["fail_flag"], cfg))
+    finally:
+        dist.destroy_process_group()
