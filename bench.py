@@ -46,6 +46,8 @@ def parse():
                     help="BASELINE config 5 instead of the headline metric: the same reads streamed from pinned host "
                          "memory as 4000-read batches through the double-buffered ppqc_submit (end to end incl. H2D)")
     ap.add_argument("--batch-reads", type=int, default=4000)
+    ap.add_argument("--dist-path", action="store_true",
+                    help="with one GPU: run the step through the multi-GPU merge path (1-rank RCCL group) to time it")
     return ap.parse_args()
 
 
@@ -61,8 +63,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (a.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or a.dist_path
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from pypore_amd import qc, synth
@@ -84,6 +88,8 @@ def main():
     cfg = dict(n_channels=a.channels, n_mux=4, n_time_bins=a.time_bins, bin_seconds=3600, time_mode=0, tz_offset_s=0,
                ref_time_s=1_528_000_000, fail_q=7.0, max_reads_hint=R)
     ctx = qc.QCContext(device=local, **cfg)
+    if use_dist:   # one stream-ordered chain of kernels and RCCL collectives, no host synchronisation in a step
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     # inputs resident in HBM before the timed region
     d_bases = torch.empty(n_bytes + 64, dtype=torch.uint8, device=dev)
@@ -103,7 +109,7 @@ def main():
         ctx.reset()
         ctx.submit_device(R, n_bytes, d_bases.data_ptr(), d_quals.data_ptr(), d_off.data_ptr(), d_ch.data_ptr(),
                           d_mux.data_ptr(), d_t.data_ptr())
-        if world > 1:
+        if use_dist:
             return finalize_distributed(ctx, dist, torch)
         return ctx.finalize()
 
@@ -164,7 +170,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a, off, d_bases, d_quals, ctx)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PPQC_ABI_VERSION 1
+#define PPQC_ABI_VERSION 2
 
 enum {
     PPQC_OK = 0,
@@ -41,6 +41,7 @@ enum {
 #define PPQC_N_LEN_LOG2 40
 #define PPQC_N_LEN_LIN 100
 #define PPQC_N_QHIST 8
+#define PPQC_N_SEL 2048     /* words of the N50 radix-select histogram (11-bit digits) */
 #define PPQC_N_GCHIST 20
 
 /* indices into ppqc_tables.totals */
@@ -160,6 +161,8 @@ typedef struct ppqc_device_tables {
     /* offsets (in u64 elements) of each table inside sum_buf */
     uint64_t off_totals, off_len_log2, off_len_lin, off_q_hist, off_gc_hist, off_hour_reads, off_hour_bases,
         off_chan_reads, off_chan_bases, off_chan_fail, off_cmh_reads, off_cmh_bases;
+    void* sel_buf; uint64_t n_sel;   /* N50 radix-select histogram (PPQC_N_SEL u64, SUM); sel_buf == sum_buf + n_sum, so
+                                        [sum_buf | sel_buf] can be all-reduced in one call of n_sum + n_sel words */
 } ppqc_device_tables;
 
 /* GPU time of the stages of the most recent calls, measured with hipEvents on the library's stream. */
@@ -217,6 +220,22 @@ int ppqc_finalize_n50(ppqc_ctx* ctx, const uint32_t* device_lengths, uint64_t n)
 int ppqc_fetch_tables(ppqc_ctx* ctx, ppqc_tables* out);
 int ppqc_finalize(ppqc_ctx* ctx, ppqc_tables* out);
 int ppqc_device_tables_view(ppqc_ctx* ctx, ppqc_device_tables* out);
+
+/* Multi-GPU N50 without gathering the lengths (no reference counterpart): exact MSD radix SELECT of the
+ * weighted median.  Round r = 0, 1, 2 looks at key bits [21,32), [10,21), [0,10).  ppqc_n50_select_hist adds, for the
+ * local lengths that match the bits chosen so far, the sum of lengths per digit into sel_buf; the caller all-reduces
+ * sel_buf (SUM; round 0 rides along with sum_buf); ppqc_n50_select_pick then chooses, from the top digit down, the
+ * first digit at which twice the weight of all longer-or-equal reads reaches the merged total (totals[N_BASES] of
+ * sum_buf), and clears sel_buf.  After the pick of round 2 the N50 is final and ppqc_fetch_tables may be called.
+ * Everything is enqueued on the context's stream; nothing synchronises with the host.  With one GPU the three
+ * hist/pick pairs back to back give the same N50 as the sort-based ppqc_finalize_n50. */
+int ppqc_n50_select_hist(ppqc_ctx* ctx, int round);
+int ppqc_n50_select_pick(ppqc_ctx* ctx, int round);
+
+/* Enqueue all further work of the context on a caller-owned HIP stream (use_external != 0; `stream` is a hipStream_t,
+ * 0 = the null stream) so that it is stream-ordered with the caller's own kernels and RCCL collectives without host
+ * synchronisation, or go back to the context's own stream (use_external == 0).  Drains the previous stream first. */
+int ppqc_set_stream(ppqc_ctx* ctx, void* stream, int use_external);
 
 int ppqc_timings(ppqc_ctx* ctx, ppqc_timing* out);
 int ppqc_reset_timings(ppqc_ctx* ctx);

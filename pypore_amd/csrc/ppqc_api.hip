@@ -53,7 +53,7 @@ struct ppqc_ctx {
     int device = 0, n_cu = 256;
     ppqc_config cfg{};
     TableParams tp{};
-    hipStream_t stream = nullptr, copy[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr, own_stream = nullptr, copy[2] = {nullptr, nullptr};
     uint64_t* lut_dev = nullptr;
 
     ReadArrays ra{};
@@ -66,7 +66,8 @@ struct ppqc_ctx {
 
     // one device allocation [sum | max | min | tmin tmax | n50 total], mirrored by one pinned host buffer
     uint64_t *res_buf = nullptr, *res_host = nullptr, res_words = 0;
-    uint64_t *sum_buf = nullptr, *max_buf = nullptr, *min_buf = nullptr, *n50_out = nullptr;
+    uint64_t *sum_buf = nullptr, *sel_buf = nullptr, *max_buf = nullptr, *min_buf = nullptr, *n50_out = nullptr,
+             *sel_state = nullptr;
     int64_t* tminmax = nullptr;
     int state = 0;   // 0 reads only, 1 extremes done, 2 tables done, 3 n50 done
     uint64_t n50 = 0;
@@ -228,7 +229,8 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
     for (int i = 0; i < 2; ++i) {
         HIPCHK(hipStreamCreateWithFlags(&c->copy[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->slot[i].copied, hipEventDisableTiming));
@@ -254,14 +256,16 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     for (int j = 0; j <= PPQC_N_QHIST; ++j) tp.thr_q[j] = q_threshold(6.0 + j);
 
     const uint64_t nch1 = 1 + (uint64_t)cfg->n_channels;
-    c->res_words = tp.lay.n_sum + 2 * nch1 + 4;
+    c->res_words = tp.lay.n_sum + PPQC_N_SEL + 2 * nch1 + 8;
     HIPCHK(hipMalloc((void**)&c->res_buf, c->res_words * 8));
     HIPCHK(hipHostMalloc((void**)&c->res_host, c->res_words * 8, hipHostMallocDefault));
     c->sum_buf = c->res_buf;
-    c->max_buf = c->sum_buf + tp.lay.n_sum;
+    c->sel_buf = c->sum_buf + tp.lay.n_sum;
+    c->max_buf = c->sel_buf + PPQC_N_SEL;
     c->min_buf = c->max_buf + nch1;
     c->tminmax = (int64_t*)(c->min_buf + nch1);
     c->n50_out = c->min_buf + nch1 + 2;
+    c->sel_state = c->n50_out + 2;
     HIPCHK(hipMalloc((void**)&c->chan_start, (uint64_t)cfg->n_channels * 4 + 64));
     HIPCHK(hipMalloc((void**)&c->first_desc, (uint64_t)cfg->n_channels * 4 + 64));
     if (cfg->max_reads_hint) CHK(ensure_reads(c, cfg->max_reads_hint));
@@ -291,7 +295,7 @@ int ppqc_destroy(ppqc_ctx* c) {
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     hipEvent_t evs[] = {c->ev_t0, c->ev_t1, c->ev_s0, c->ev_s1};
     for (auto e : evs) if (e) (void)hipEventDestroy(e);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return PPQC_OK;
 }
@@ -502,7 +506,7 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     HIPCHK(hipEventRecord(c->ev_t0, s));
-    HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum, 1 + (uint64_t)c->cfg.n_channels, s));
+    HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, s));
     HIPCHK(launch_extremes(c->ra, c->n_reads, c->tp, c->max_buf, c->min_buf, c->tminmax, s));
     c->state = 1;
     return PPQC_OK;
@@ -549,9 +553,9 @@ int ppqc_finalize_n50(ppqc_ctx* c, const uint32_t* dlens, uint64_t n) {
     if (!dlens) { dlens = c->ra.lens32; n = c->n_reads; }
     if (n >= (1ull << 32)) return fail(PPQC_E_RANGE, "more than 2^32-1 lengths");
     HIPCHK(hipEventRecord(c->ev_s0, s));
-    HIPCHK(hipMemcpyAsync(c->res_host + c->tp.lay.n_sum, c->max_buf, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(c->res_host + c->tp.lay.n_sum + PPQC_N_SEL, c->max_buf, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    const uint64_t maxlen = c->res_host[c->tp.lay.n_sum];
+    const uint64_t maxlen = c->res_host[c->tp.lay.n_sum + PPQC_N_SEL];
     CHK(ensure_sort32(c, n ? n : 1));
     if (n) HIPCHK(hipMemcpyAsync(c->sk32, dlens, n * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(sort_u32(c->sk32, c->sk32_tmp, n, c->counts, bytes_mask_for(maxlen), s));
@@ -579,7 +583,7 @@ int ppqc_fetch_tables(ppqc_ctx* c, ppqc_tables* o) {
     OUT(o->chan_bases, l.off_chan_bases, nch); OUT(o->chan_fail, l.off_chan_fail, nch);
     OUT(o->cmh_reads, l.off_cmh_reads, cells); OUT(o->cmh_bases, l.off_cmh_bases, cells);
 #undef OUT
-    const uint64_t* mx = h + l.n_sum;
+    const uint64_t* mx = h + l.n_sum + PPQC_N_SEL;
     const uint64_t* mn = mx + 1 + nch;
     if (o->chan_max_len) memcpy(o->chan_max_len, mx + 1, nch * 8);
     if (o->chan_min_len) memcpy(o->chan_min_len, mn + 1, nch * 8);
@@ -612,6 +616,45 @@ int ppqc_device_tables_view(ppqc_ctx* c, ppqc_device_tables* o) {
     o->off_q_hist = l.off_q_hist; o->off_gc_hist = l.off_gc_hist; o->off_hour_reads = l.off_hour_reads;
     o->off_hour_bases = l.off_hour_bases; o->off_chan_reads = l.off_chan_reads; o->off_chan_bases = l.off_chan_bases;
     o->off_chan_fail = l.off_chan_fail; o->off_cmh_reads = l.off_cmh_reads; o->off_cmh_bases = l.off_cmh_bases;
+    o->sel_buf = c->sel_buf; o->n_sel = PPQC_N_SEL;
+    return PPQC_OK;
+}
+
+static const int kSelShift[3] = {21, 10, 0}, kSelBits[3] = {11, 11, 10};
+
+int ppqc_n50_select_hist(ppqc_ctx* c, int round) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    if (round < 0 || round > 2) return fail(PPQC_E_INVALID, "round must be 0, 1 or 2");
+    if (c->state < 1) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes first");
+    HIPCHK(hipSetDevice(c->device));
+    if (round == 0) HIPCHK(hipEventRecord(c->ev_s0, c->stream));
+    HIPCHK(launch_select_hist(c->ra.lens32, c->n_reads, kSelShift[round], kSelBits[round], c->sel_state, c->sel_buf,
+                              c->stream));
+    return PPQC_OK;
+}
+
+int ppqc_n50_select_pick(ppqc_ctx* c, int round) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    if (round < 0 || round > 2) return fail(PPQC_E_INVALID, "round must be 0, 1 or 2");
+    if (c->state < 2) return fail(PPQC_E_STATE, "call ppqc_finalize_tables first (the pick needs the merged total)");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(launch_select_pick(c->sel_buf, c->sum_buf + c->tp.lay.off_totals + PPQC_TOT_N_BASES, c->sel_state,
+                              kSelShift[round], kSelBits[round], round == 2, c->n50_out, c->stream));
+    if (round == 2) {
+        HIPCHK(hipEventRecord(c->ev_s1, c->stream));
+        HIPCHK(hipEventRecord(c->ev_t1, c->stream));
+        c->state = 3;
+    }
+    return PPQC_OK;
+}
+
+int ppqc_set_stream(ppqc_ctx* c, void* stream, int use_external) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t ns = use_external ? (hipStream_t)stream : c->own_stream;
+    if (ns == c->stream) return PPQC_OK;
+    CHK(ppqc_sync(c));
+    c->stream = ns;
     return PPQC_OK;
 }
 

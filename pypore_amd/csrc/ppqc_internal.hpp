@@ -90,8 +90,9 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
                          hipStream_t s);
 
 hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s);
-// res = [n_sum sums = 0 | nch1 max = 0 | nch1 min = INT64_MAX | tmin = INT64_MAX, tmax = INT64_MIN | n50, total = 0]
-hipError_t launch_init_results(uint64_t* res, uint64_t n_sum, uint64_t nch1, hipStream_t s);
+// res = [n_zero sums (tables + select histogram) = 0 | nch1 max = 0 | nch1 min = INT64_MAX | tmin = INT64_MAX,
+//        tmax = INT64_MIN | n50, total = 0 | 4 words of select state = 0]
+hipError_t launch_init_results(uint64_t* res, uint64_t n_zero, uint64_t nch1, hipStream_t s);
 
 // time_mode 1 helpers
 hipError_t launch_mode1_keys(ReadArrays ra, uint64_t n, const TableParams& tp, const int64_t* tminmax, uint64_t* keys,
@@ -111,6 +112,14 @@ hipError_t sort_u64_pairs(uint64_t* keys, uint64_t* tmp_keys, uint32_t* vals, ui
 // N50 over ascending-sorted lengths: out[0] = n50, out[1] = total bases.  block_sums has n/2048 + 2 u64.
 uint64_t n50_block_words(uint64_t n);
 hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s);
+
+// Exact N50 by MSD radix select (multi-GPU path).  state = {prefix, weight of all longer keys}; sel = PPQC_N_SEL u64.
+// hist: sel[d] += sum of the lengths whose bits above `shift + nbits` equal the prefix and whose digit is d.
+// pick: chooses the digit (see include/pypore_qc.h), updates state, zeroes sel; `last` also writes out[0] = N50, out[1] = total.
+hipError_t launch_select_hist(const uint32_t* lens, uint64_t n, int shift, int nbits, const uint64_t* state,
+                              uint64_t* sel, hipStream_t s);
+hipError_t launch_select_pick(uint64_t* sel, const uint64_t* total, uint64_t* state, int shift, int nbits, bool last,
+                              uint64_t* out, hipStream_t s);
 
 hipError_t launch_synth(uint8_t* bases, uint8_t* quals, uint64_t first, uint64_t n, uint64_t seed, hipStream_t s);
 

@@ -243,4 +243,85 @@ hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, 
     return hipGetLastError();
 }
 
+// ---- N50 by weighted radix select (multi-GPU: only PPQC_N_SEL-word histograms cross xGMI) --------------------------
+__global__ __launch_bounds__(256) void select_hist_kernel(const uint32_t* __restrict__ lens, uint64_t n, int shift,
+                                                          int nbits, const uint64_t* __restrict__ state,
+                                                          uint64_t* __restrict__ sel) {
+    __shared__ unsigned long long h[PPQC_N_SEL];
+    for (int d = threadIdx.x; d < PPQC_N_SEL; d += blockDim.x) h[d] = 0;
+    const uint32_t prefix = (uint32_t)state[0];
+    const uint32_t mask_hi = shift + nbits >= 32 ? 0u : ~0u << (shift + nbits);
+    const uint32_t want = prefix & mask_hi, dmask = (1u << nbits) - 1u;
+    __syncthreads();
+    // equal digits come in runs (most reads share their top bits): combine a run in registers, one LDS atomic per run
+    int last_d = -1;
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t k = lens[i];
+        if (k == 0 || (k & mask_hi) != want) continue;
+        const int d = (int)((k >> shift) & dmask);
+        if (d != last_d) {
+            if (last_d >= 0) atomicAdd(&h[last_d], acc);
+            last_d = d;
+            acc = 0;
+        }
+        acc += k;
+    }
+    if (last_d >= 0) atomicAdd(&h[last_d], acc);
+    __syncthreads();
+    for (int d = threadIdx.x; d < PPQC_N_SEL; d += blockDim.x)
+        if (h[d]) atomicAdd((unsigned long long*)&sel[d], h[d]);
+}
+
+// One block.  pred(d) = 2 * (above + sum_{d' >= d} sel[d']) >= total is monotone; the chosen digit is the largest d
+// with pred(d): the weight of strictly longer keys stays below half the total, with digit d included it reaches it.
+__global__ __launch_bounds__(256) void select_pick_kernel(uint64_t* __restrict__ sel, const uint64_t* __restrict__ total,
+                                                          uint64_t* __restrict__ state, int shift, int nbits, int last,
+                                                          uint64_t* __restrict__ out) {
+    __shared__ uint64_t part[256];
+    const uint32_t t = threadIdx.x;
+    const int per = (1 << nbits) / 256;   // 8 or 4 digits per thread
+    const uint64_t T = total[0], prefix = state[0], above = state[1];
+    uint64_t w[8], loc = 0;
+    for (int k = 0; k < per; ++k) { w[k] = sel[t * per + k]; loc += w[k]; }
+    part[t] = loc;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t run = 0;
+        for (int i = 255; i >= 0; --i) { const uint64_t x = part[i]; part[i] = run; run += x; }
+    }
+    __syncthreads();
+    uint64_t after = above + part[t];
+    for (int k = per - 1; k >= 0; --k) {
+        const uint64_t suf = after + w[k];
+        if (T != 0 && 2 * suf >= T && 2 * after < T) {
+            const uint64_t np = prefix | ((uint64_t)(t * per + k) << shift);
+            state[0] = np;
+            state[1] = after;
+            if (last) out[0] = np;
+        }
+        after = suf;
+    }
+    for (int d = t; d < PPQC_N_SEL; d += 256) sel[d] = 0;
+    if (last && t == 0) {
+        out[1] = T;
+        if (T == 0) out[0] = 0;
+    }
+}
+
+hipError_t launch_select_hist(const uint32_t* lens, uint64_t n, int shift, int nbits, const uint64_t* state,
+                              uint64_t* sel, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(select_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, s, lens, n, shift, nbits, state, sel);
+    return hipGetLastError();
+}
+
+hipError_t launch_select_pick(uint64_t* sel, const uint64_t* total, uint64_t* state, int shift, int nbits, bool last,
+                              uint64_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, s, sel, total, state, shift, nbits, last ? 1 : 0, out);
+    return hipGetLastError();
+}
+
 }  // namespace ppqc

@@ -270,7 +270,7 @@ hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const u
 }
 
 __global__ void init_results_kernel(uint64_t* res, uint64_t n_sum, uint64_t nch1) {
-    const uint64_t total = n_sum + 2 * nch1 + 4;
+    const uint64_t total = n_sum + 2 * nch1 + 8;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t v = 0;
         if (i >= n_sum + nch1 && i < n_sum + 2 * nch1) v = (uint64_t)INT64_MAX;          // min section
@@ -280,7 +280,7 @@ __global__ void init_results_kernel(uint64_t* res, uint64_t n_sum, uint64_t nch1
     }
 }
 hipError_t launch_init_results(uint64_t* res, uint64_t n_sum, uint64_t nch1, hipStream_t s) {
-    const uint64_t total = n_sum + 2 * nch1 + 4;
+    const uint64_t total = n_sum + 2 * nch1 + 8;
     uint64_t blocks = (total + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(init_results_kernel, dim3((unsigned)blocks), dim3(256), 0, s, res, n_sum, nch1);

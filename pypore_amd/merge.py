@@ -9,7 +9,8 @@ FastStats (lib/seq_routines.py:103-108):
   1. all-reduce MAX on [max_len | chan_max_len], MIN on [min_pos_len | chan_min_len]   (a few KB)
   2. all-reduce SUM on the fused u64 table buffer (1.6 MB at 512x4x48, 13.9 MB at 3000x4x72) -- one call; at these
      sizes the ring is latency-bound on xGMI, so it is not bucketed or pipelined
-  3. all-gather of the u32 read lengths (4 MB per 1e6 reads), then every rank runs the same radix sort + N50
+  3. exact N50 by weighted radix select: three 2048-word histograms all-reduced (the first fused into step 2); the
+     alternative (n50="gather") all-gathers the u32 lengths and sorts them on every rank
 
 time_mode 1 (the reference's per-channel hour-wrap quirk) needs all reads of a channel on one rank: shard by channel.
 """
@@ -36,19 +37,38 @@ def gather_lengths(lengths_t, dist, torch, group=None):
     return out
 
 
-def finalize_distributed(ctx, dist, torch, group=None):
-    """Phased finalize of a QCContext with RCCL merges in between; returns the merged tables on every rank."""
+def finalize_distributed(ctx, dist, torch, group=None, n50="select"):
+    """Phased finalize of a QCContext with RCCL merges in between; returns the merged tables on every rank.
+
+    The context is put on torch's current stream, so its kernels and the collectives (which torch orders against that
+    stream with events) form one stream-ordered chain: nothing synchronises with the host before the final fetch.
+
+    ``n50="select"`` (default): exact N50 by weighted radix select -- three rounds, each a 2048-word histogram that is
+    all-reduced (the first one rides along with the table buffer), so only small tables cross xGMI and the cost does
+    not grow with the number of ranks.  ``n50="gather"``: all-gather the u32 lengths and run the LSD radix sort + N50
+    on every rank (the single-GPU algorithm; its sort grows with the whole job)."""
+    handle = torch.cuda.current_stream().cuda_stream
+    if ctx.external_stream != handle:
+        ctx.set_stream(handle)
     ctx.finalize_extremes()
     views, _ = ctx.device_tables()
     t_max = torch.as_tensor(views["max"], device="cuda")
     t_min = torch.as_tensor(views["min"], device="cuda")
-    t_sum = torch.as_tensor(views["sum"], device="cuda")
-    ctx.sync()                                   # library stream -> host; torch's stream picks up from here
     dist.all_reduce(t_max, op=dist.ReduceOp.MAX, group=group)
     dist.all_reduce(t_min, op=dist.ReduceOp.MIN, group=group)
-    torch.cuda.current_stream().synchronize()
     ctx.finalize_tables()                        # length histogram bins use the merged max_len
-    ctx.sync()
+    if n50 == "select":
+        t_sum_sel = torch.as_tensor(views["sum_sel"], device="cuda")
+        t_sel = torch.as_tensor(views["sel"], device="cuda")
+        ctx.n50_select_hist(0)
+        dist.all_reduce(t_sum_sel, op=dist.ReduceOp.SUM, group=group)      # tables + first select histogram
+        ctx.n50_select_pick(0)
+        for r in (1, 2):
+            ctx.n50_select_hist(r)
+            dist.all_reduce(t_sel, op=dist.ReduceOp.SUM, group=group)
+            ctx.n50_select_pick(r)
+        return ctx.fetch_tables()
+    t_sum = torch.as_tensor(views["sum"], device="cuda")
     dist.all_reduce(t_sum, op=dist.ReduceOp.SUM, group=group)
     n_local = views["lengths"].__cuda_array_interface__["shape"][0]
     if n_local:
@@ -56,9 +76,42 @@ def finalize_distributed(ctx, dist, torch, group=None):
     else:
         lens = torch.zeros(0, dtype=torch.int32, device="cuda")
     all_lens = gather_lengths(lens, dist, torch, group)
-    torch.cuda.current_stream().synchronize()
     ctx.finalize_n50(all_lens.data_ptr(), all_lens.numel())
-    return ctx.fetch_tables()
+    tables = ctx.fetch_tables()                  # synchronises: all_lens may be released afterwards
+    return tables
+
+
+SELECT_ROUNDS = ((21, 11), (10, 11), (0, 10))    # (shift, bits) of ppqc_n50_select_hist / _pick
+
+
+def n50_select_reference(local_lengths, all_reduce_sum):
+    """The arithmetic of the select path on host arrays, for tests: ``local_lengths`` is this rank's uint32 vector,
+    ``all_reduce_sum(np_int64_array)`` merges a histogram (or a scalar) across ranks in place."""
+    import numpy as np
+    lens = np.asarray(local_lengths, dtype=np.uint32)
+    total = np.array([int(lens.sum(dtype=np.uint64))], dtype=np.int64)
+    all_reduce_sum(total)
+    T = int(total[0])
+    prefix, above = 0, 0
+    for shift, bits in SELECT_ROUNDS:
+        hi = shift + bits
+        m = np.ones(len(lens), bool) if hi >= 32 else ((lens >> np.uint32(hi)) == (prefix >> hi))
+        m &= lens > 0
+        digit = ((lens[m] >> np.uint32(shift)) & np.uint32((1 << bits) - 1)).astype(np.int64)
+        w = np.zeros(1 << bits, dtype=np.int64)
+        np.add.at(w, digit, lens[m].astype(np.int64))
+        all_reduce_sum(w)
+        if T == 0:
+            continue
+        after = above
+        for d in range((1 << bits) - 1, -1, -1):
+            suf = after + int(w[d])
+            if 2 * suf >= T and 2 * after < T:
+                prefix |= d << shift
+                above = after
+                break
+            after = suf
+    return prefix if T else 0
 
 
 def merge_tables_host(tables_list):

@@ -40,6 +40,7 @@ class QCContext:
         self.cfg = cfg
         self._ctx = C.c_void_p()
         L.check(self._lib.ppqc_create(C.byref(self._ctx), int(device), C.byref(cfg)))
+        self.external_stream = None
         self._keep = {}   # per staging slot: host arrays that must outlive the asynchronous submit
 
     # -- lifetime ---------------------------------------------------------------------------------
@@ -177,6 +178,27 @@ class QCContext:
     def finalize_n50(self, lengths_ptr=None, n=0):
         L.check(self._lib.ppqc_finalize_n50(self._ctx, lengths_ptr, int(n)))
 
+    def n50_select_hist(self, rnd):
+        L.check(self._lib.ppqc_n50_select_hist(self._ctx, int(rnd)))
+
+    def n50_select_pick(self, rnd):
+        L.check(self._lib.ppqc_n50_select_pick(self._ctx, int(rnd)))
+
+    def n50_select(self):
+        """Single-GPU run of the multi-GPU N50 path (three histogram / pick rounds, no collectives in between)."""
+        for r in range(3):
+            self.n50_select_hist(r)
+            self.n50_select_pick(r)
+
+    def set_stream(self, stream_handle):
+        """Enqueue on a caller-owned HIP stream (``torch.cuda.current_stream().cuda_stream``; 0 = null stream)."""
+        L.check(self._lib.ppqc_set_stream(self._ctx, C.c_void_p(int(stream_handle)), 1))
+        self.external_stream = int(stream_handle)
+
+    def use_own_stream(self):
+        L.check(self._lib.ppqc_set_stream(self._ctx, None, 0))
+        self.external_stream = None
+
     def fetch_tables(self):
         arr, t = self._alloc_tables()
         L.check(self._lib.ppqc_fetch_tables(self._ctx, C.byref(t)))
@@ -189,7 +211,9 @@ class QCContext:
         views = dict(sum=DeviceArrayView(d.sum_buf, d.n_sum, "<i8", self),
                      max=DeviceArrayView(d.max_buf, d.n_max, "<i8", self),
                      min=DeviceArrayView(d.min_buf, d.n_min, "<i8", self),
-                     lengths=DeviceArrayView(d.lengths, d.n_lengths, "<i4", self))
+                     lengths=DeviceArrayView(d.lengths, d.n_lengths, "<i4", self),
+                     sel=DeviceArrayView(d.sel_buf, d.n_sel, "<i8", self),
+                     sum_sel=DeviceArrayView(d.sum_buf, d.n_sum + d.n_sel, "<i8", self))
         return views, d
 
     def timings(self):

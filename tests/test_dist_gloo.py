@@ -56,6 +56,15 @@ def _worker(rank, world, port, tmp):
         assert int(t_min[0]) == want["min_pos_len"] and np.array_equal(t_min[1:].numpy(), want["chan_min_len"])
         assert all_lens.numel() == 2 * max(R // 3, R - R // 3)
         assert co.n50(all_lens.numpy().astype(np.uint32)) == want["n50"]
+        # the select path (bench.py --gpus N): same N50 from three all-reduced 2048-word histograms, no gather
+        def ar(a):
+            t = torch.from_numpy(a)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        assert merge.n50_select_reference(lens.astype(np.uint32), ar) == want["n50"]
+        for case in ([[5], []], [[2, 2, 2, 3], [3, 4, 8, 8]], [[], []], [[1 << 31, 7], [(1 << 31) + 5, 1 << 22]],
+                     [[2_000_000] * 3, list(range(1, 3000))]):
+            mine = np.asarray(case[rank], dtype=np.uint32)
+            assert merge.n50_select_reference(mine, ar) == po.n50([int(x) for x in case[0] + case[1]]), case
         hm = merge.merge_tables_host([loc, loc])
         assert np.array_equal(hm["chan_reads"], 2 * np.asarray(loc["chan_reads"]))
         open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")

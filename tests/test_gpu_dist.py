@@ -30,8 +30,15 @@ def test_finalize_distributed_one_rank_nccl_and_zero_copy_views(c_oracle):
         b = random_batch(5, 20000, 300, n_channels=3000, hours=75)
         with qc.QCContext(device=0, **cfg) as ctx:
             ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], b["fail_flag"])
-            merged = finalize_distributed(ctx, dist, torch)
+            merged = finalize_distributed(ctx, dist, torch)                  # N50 by radix select (default)
+            assert ctx.external_stream == torch.cuda.current_stream().cuda_stream
+            ctx.reset()
+            ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], b["fail_flag"])
+            gathered = finalize_distributed(ctx, dist, torch, n50="gather")   # all-gather + sort on every rank
+            assert_tables_equal(merged, gathered, "select vs gather")
             views, d = ctx.device_tables()
+            assert d.sel_buf == d.sum_buf + 8 * d.n_sum and d.n_sel == 2048      # [sum | sel] is one all-reduce
+            ctx.use_own_stream()
             t_sum = torch.as_tensor(views["sum"], device="cuda")
             assert t_sum.data_ptr() == d.sum_buf and t_sum.numel() == d.n_sum      # in-place collectives need zero copy
             lens = torch.as_tensor(views["lengths"], device="cuda")

@@ -330,3 +330,28 @@ def test_fastq_text_to_tables(qc, c_oracle):
     want = c_oracle.per_read(p["bases"], p["quals"], p["offsets"], nthreads=2)
     _check_reads(got, want)
     assert_tables_equal(tables, c_oracle.tables(want, p["channel"], mux, p["start_time"], None, cfg))
+
+
+def test_n50_radix_select_equals_sort(qc, c_oracle):
+    """The multi-GPU N50 path (three histogram / pick rounds) run on one GPU against the LSD-sort N50 and the oracle."""
+    rng = np.random.default_rng(17)
+    cases = [[2, 2, 2, 3, 3, 4, 8, 8], [10, 20, 30, 40, 50], [5], [0, 0, 0], [7] * 5000, [1, 2_000_000],
+             rng.integers(1, 2_000_000, 70_001).tolist(), rng.integers(1, 4000, 300_000).tolist(),
+             np.rint(rng.lognormal(8.5, 1.2, 200_000)).astype(np.int64).clip(1, 2_000_000).tolist()]
+    for lens in cases:
+        R = len(lens)
+        off = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+        nb = int(off[-1])
+        with qc.QCContext(device=0, **BASE_CFG) as ctx:
+            ctx.submit(np.full(nb, ord("A"), np.uint8), np.full(nb, 50, np.uint8), off, np.ones(R, np.uint32),
+                       np.ones(R, np.uint8), np.full(R, 1_528_000_000, np.int64))
+            ctx.finalize_extremes()
+            ctx.finalize_tables()
+            ctx.n50_select()
+            a = ctx.fetch_tables()
+            ctx.finalize_extremes()
+            ctx.finalize_tables()
+            ctx.finalize_n50()
+            b = ctx.fetch_tables()
+        assert a["n50"] == b["n50"] == c_oracle.n50(lens), (lens[:8], a["n50"], b["n50"])
+        assert_tables_equal(a, b)
