@@ -80,7 +80,8 @@ struct ppqc_ctx {
 
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> ev_pool;
-    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr, ev_max = nullptr;
+    uint64_t* maxlen_host = nullptr;   // pinned word: max_len lands here right after the extremes kernel
     ppqc_timing timing{};
 };
 
@@ -238,6 +239,8 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     }
     HIPCHK(hipEventCreate(&c->ev_t0)); HIPCHK(hipEventCreate(&c->ev_t1));
     HIPCHK(hipEventCreate(&c->ev_s0)); HIPCHK(hipEventCreate(&c->ev_s1));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_max, hipEventDisableTiming));
+    HIPCHK(hipHostMalloc((void**)&c->maxlen_host, 64, hipHostMallocDefault));
 
     // error-probability LUT: e[b] = round(2^52 * 10^(-q/10)), q = clamp(b - 33, 0, 93)
     uint64_t lut[256];
@@ -283,6 +286,8 @@ int ppqc_destroy(ppqc_ctx* c) {
                     c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->res_host) (void)hipHostFree(c->res_host);
+    if (c->maxlen_host) (void)hipHostFree(c->maxlen_host);
+    if (c->ev_max) (void)hipEventDestroy(c->ev_max);
     for (int i = 0; i < 2; ++i) {
         Slot& s = c->slot[i];
         void* sp[] = {s.bases, s.quals, s.mux, s.ff, s.offsets, s.channel, s.time};
@@ -508,6 +513,10 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     HIPCHK(hipEventRecord(c->ev_t0, s));
     HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, s));
     HIPCHK(launch_extremes(c->ra, c->n_reads, c->tp, c->max_buf, c->min_buf, c->tminmax, s));
+    // the sort needs max_len on the host (which key bytes to pass over): fetch it now, so that the round trip hides
+    // behind the tables kernel instead of draining the stream later (a merged max_len only adds passes, never loses one)
+    HIPCHK(hipMemcpyAsync(c->maxlen_host, c->max_buf, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(c->ev_max, s));
     c->state = 1;
     return PPQC_OK;
 }
@@ -553,9 +562,15 @@ int ppqc_finalize_n50(ppqc_ctx* c, const uint32_t* dlens, uint64_t n) {
     if (!dlens) { dlens = c->ra.lens32; n = c->n_reads; }
     if (n >= (1ull << 32)) return fail(PPQC_E_RANGE, "more than 2^32-1 lengths");
     HIPCHK(hipEventRecord(c->ev_s0, s));
-    HIPCHK(hipMemcpyAsync(c->res_host + c->tp.lay.n_sum + PPQC_N_SEL, c->max_buf, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    const uint64_t maxlen = c->res_host[c->tp.lay.n_sum + PPQC_N_SEL];
+    uint64_t maxlen;
+    if (dlens == c->ra.lens32) {   // local lengths: the copy enqueued by ppqc_finalize_extremes
+        HIPCHK(hipEventSynchronize(c->ev_max));
+        maxlen = *c->maxlen_host;
+    } else {                       // gathered lengths of other ranks: bounded by the merged max_len
+        HIPCHK(hipMemcpyAsync(c->maxlen_host, c->max_buf, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        maxlen = *c->maxlen_host;
+    }
     CHK(ensure_sort32(c, n ? n : 1));
     if (n) HIPCHK(hipMemcpyAsync(c->sk32, dlens, n * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(sort_u32(c->sk32, c->sk32_tmp, n, c->counts, bytes_mask_for(maxlen), s));

@@ -4,6 +4,8 @@
 // Replaces the aggregation of parsing_func (lib/fast5_reader.py:117-145 == lib/multi_read_fast5_reader.py:47-77), the
 // sums of FastStats (lib/seq_routines.py:99-137) and the per-channel tables of result_plotting / ChannelPlotter_f
 // (:378-394, :507-514, :673-680).  All cells are u64 so one RCCL dtype covers the merged buffer.
+#include <stdlib.h>
+
 #include "ppqc_internal.hpp"
 
 namespace ppqc {
@@ -21,7 +23,7 @@ __device__ __forceinline__ int32_t hour_of_day(int64_t t, const TableParams& tp)
 // ---- pass 1: extremes, sort input, absolute hour bins --------------------------------------------------------------
 // Per-channel min/max are privatised in LDS (u32 pairs, dynamic: 8 B per channel) when they fit, and flushed once per
 // block; run extremes go through thread-local registers, one LDS atomic per thread, one global atomic per block.
-__global__ __launch_bounds__(256) void extremes_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* max_buf,
+__global__ __launch_bounds__(1024) void extremes_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* max_buf,
                                                        uint64_t* min_buf, int64_t* tminmax, uint32_t nchL) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* s_cmax = reinterpret_cast<uint32_t*>(smem);
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void extremes_kernel(ReadArrays ra, uint64_t n
 //   u64 totals[16] | u64 hour_bases[nb] | u64 chan_bases[nchL] |
 //   u32 len_log2[40] | u32 len_lin[100] | u32 q[8] | u32 gc[20] | u32 hour_reads[nb] | u32 chan_reads[nchL] | u32 chan_fail[nchL]
 // nchL = n_channels when the per-channel accumulators fit in LDS, else 0 (then they go straight to global atomics).
-__global__ __launch_bounds__(256) void tables_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf,
+__global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf,
                                                      const uint64_t* max_buf, uint32_t nchL) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t nb = tp.lay.n_time_bins, nch = tp.lay.n_channels, nmux = tp.lay.n_mux;
@@ -287,6 +289,12 @@ hipError_t launch_init_results(uint64_t* res, uint64_t n_sum, uint64_t nch1, hip
     return hipGetLastError();
 }
 
+static inline unsigned env_or(const char* name, unsigned dflt) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? (unsigned)v : dflt;
+}
+
 static inline unsigned grid_for(uint64_t n, unsigned cap) {
     uint64_t b = (n + 255) / 256;
     if (b < 1) b = 1;
@@ -298,8 +306,9 @@ hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uin
     if (n == 0) return hipSuccess;
     // a length of 2^32-1 cannot be told from "unseen" in the u32 LDS copy: lengths are < 2^32-1 by the API contract
     const uint32_t nchL = tp.lay.n_channels <= 8192 ? tp.lay.n_channels : 0;
-    hipLaunchKernelGGL(extremes_kernel, dim3(grid_for(n, 512)), dim3(256), (size_t)nchL * 8, s, ra, n, tp, max_buf,
-                       min_buf, tminmax, nchL);
+    hipLaunchKernelGGL(extremes_kernel, dim3(grid_for(n, env_or("PPQC_EXT_BLOCKS", 256))),
+                       dim3(env_or("PPQC_EXT_THREADS", 512)), (size_t)nchL * 8, s, ra, n, tp, max_buf, min_buf, tminmax,
+                       nchL);
     return hipGetLastError();
 }
 
@@ -312,8 +321,10 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
     const size_t lds = 8ull * (PPQC_N_TOTALS + nb + nchL) +
                        4ull * (PPQC_N_LEN_LOG2 + PPQC_N_LEN_LIN + PPQC_N_QHIST + PPQC_N_GCHIST + nb + 2ull * nchL);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    // few, fat blocks: every block flushes its private tables once
-    hipLaunchKernelGGL(tables_kernel, dim3(grid_for(n, 512)), dim3(256), lds, s, ra, n, tp, sum_buf, max_buf, nchL);
+    // few, fat blocks: every block flushes its private tables once (measured on MI355X, config 2: 256 x 512 threads
+    // 0.317 ms for the whole finalize, 512 x 256: 0.34, 2048 x 256: 0.42; PPQC_TAB_* / PPQC_EXT_* are A/B knobs)
+    hipLaunchKernelGGL(tables_kernel, dim3(grid_for(n, env_or("PPQC_TAB_BLOCKS", 256))),
+                       dim3(env_or("PPQC_TAB_THREADS", 512)), lds, s, ra, n, tp, sum_buf, max_buf, nchL);
     return hipGetLastError();
 }
 

@@ -144,7 +144,7 @@ class QCContext:
 
     def _alloc_tables(self):
         nch, nmux, nb = self.cfg.n_channels, self.cfg.n_mux, self.cfg.n_time_bins
-        z = lambda *s: np.zeros(s, dtype=np.uint64)
+        z = lambda *s: np.empty(s, dtype=np.uint64)      # every table is overwritten by the fetch
         arr = dict(totals=z(L.N_TOTALS), len_hist_log2=z(L.N_LEN_LOG2), len_hist_lin=z(L.N_LEN_LIN),
                    q_hist=z(L.N_QHIST), gc_hist=z(L.N_GCHIST), hour_reads=z(nb), hour_bases=z(nb), chan_reads=z(nch),
                    chan_bases=z(nch), chan_fail=z(nch), cmh_reads=z(nch, nmux, nb), cmh_bases=z(nch, nmux, nb),
@@ -156,7 +156,7 @@ class QCContext:
 
     @staticmethod
     def _tables_dict(arr, t):
-        out = {k: a.astype(np.int64) for k, a in arr.items()}   # two's complement view (qsum may be negative)
+        out = {k: a.view(np.int64) for k, a in arr.items()}   # two's complement view (qsum may be negative)
         out.update(max_len=int(t.max_len), min_pos_len=int(t.min_pos_len), lin_bin_width=int(t.lin_bin_width),
                    n50=int(t.n50))
         return out
