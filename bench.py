@@ -233,6 +233,11 @@ def pmc_traffic(alg_bytes):
     return {}
 
 
+def synth_meta(a, R):
+    from pypore_amd import synth
+    return synth.metadata(R, a.channels, a.time_bins, a.seed)
+
+
 def cpu_baseline(a, off, d_bases, d_quals, ctx):
     """The C oracle ("port" of the reference's per-read arithmetic) on the host cores, on a bounded sample of the
     same workload: a prefix of at most 2 Gbases, passed over repeatedly until about 12 s of CPU work have been
@@ -256,7 +261,19 @@ def cpu_baseline(a, off, d_bases, d_quals, ctx):
         co.per_read(hb, hq, sub, nthreads=cores)
         dt += time.perf_counter() - t0
         passes += 1
+    # the same statistics organised the way the reference organises them (pure Python, one task per channel on a
+    # pool of `cores` processes), on a smaller prefix: SURVEY.md 8d's "reference-shaped" figure
+    from oracle import ref_shaped
+    r2 = min(r, 40_000)
+    nb2 = int(off[r2])
+    ch, mux, t = synth_meta(a, len(off) - 1)
+    dt2, _cd = ref_shaped.run(hb[:nb2], sub[: r2 + 1], ch[:r2], mux[:r2], t[:r2], got["mean_q"][:r2], 1_528_000_000, cores)
+    shaped = {"value": round(nb2 / dt2 / 1e9, 4), "unit": "Gbases/s", "cores": cores,
+              "sample": "first %d reads (%.2f Gbases), oracle/ref_shaped.py: multiprocessing pool, one task per "
+                        "channel, GC() as six count passes, parsing_func aggregation; HDF5 / dateutil / Biopython "
+                        "record costs of the real reference excluded, %.1f s" % (r2, nb2 / 1e9, dt2)}
     return {"value": round(nb * passes / dt / 1e9, 3), "unit": "Gbases/s", "cores": cores, "kind": "port",
+            "reference_shaped_python": shaped,
             "sample": "first %d reads (%.2f Gbases) of the same workload x %d passes, oracle/ppqc_oracle.c per-read "
                       "statistics, %d pthreads, %.1f s timed" % (r, nb / 1e9, passes, cores, dt),
             "gpu_matches_cpu_on_sample": bool(ok)}
