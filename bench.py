@@ -264,7 +264,7 @@ def cpu_baseline(a, off, d_bases, d_quals, ctx):
     # the same statistics organised the way the reference organises them (pure Python, one task per channel on a
     # pool of `cores` processes), on a smaller prefix: SURVEY.md 8d's "reference-shaped" figure
     from oracle import ref_shaped
-    r2 = min(r, 40_000)
+    r2 = min(r, 200_000)
     nb2 = int(off[r2])
     ch, mux, t = synth_meta(a, len(off) - 1)
     dt2, _cd = ref_shaped.run(hb[:nb2], sub[: r2 + 1], ch[:r2], mux[:r2], t[:r2], got["mean_q"][:r2], 1_528_000_000, cores)
