@@ -260,8 +260,10 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
 
     const uint64_t nch1 = 1 + (uint64_t)cfg->n_channels;
     c->res_words = tp.lay.n_sum + PPQC_N_SEL + 2 * nch1 + 8;
-    HIPCHK(hipMalloc((void**)&c->res_buf, c->res_words * 8));
-    HIPCHK(hipHostMalloc((void**)&c->res_host, c->res_words * 8, hipHostMallocDefault));
+    // one extra word behind the results: the count of malformed device-CSR rows (never touched by init_results)
+    HIPCHK(hipMalloc((void**)&c->res_buf, (c->res_words + 1) * 8));
+    HIPCHK(hipMemset(c->res_buf + c->res_words, 0, 8));
+    HIPCHK(hipHostMalloc((void**)&c->res_host, (c->res_words + 1) * 8, hipHostMallocDefault));
     c->sum_buf = c->res_buf;
     c->sel_buf = c->sum_buf + tp.lay.n_sum;
     c->max_buf = c->sel_buf + PPQC_N_SEL;
@@ -309,6 +311,7 @@ int ppqc_reset(ppqc_ctx* c) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemsetAsync(c->res_buf + c->res_words, 0, 8, c->stream));
     c->n_reads = 0;
     c->state = 0;
     c->n50 = 0;
@@ -344,7 +347,8 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->n_cu, s));
     HIPCHK(hipEventRecord(ev.b, s));
     c->pending.push_back(ev);
-    HIPCHK(launch_finalize_reads(v, c->ra, base, c->head, c->tail, c->tp.thr_fail, c->tp.fail_q, s));
+    HIPCHK(launch_finalize_reads(v, c->ra, base, c->head, c->tail, c->tp.thr_fail, c->tp.fail_q,
+                                 c->res_buf + c->res_words, s));
     c->n_reads += R;
     c->state = 0;
     return PPQC_OK;
@@ -487,6 +491,9 @@ int ppqc_read_stats(ppqc_ctx* c, const ppqc_per_read* o, uint64_t first, uint64_
     if (first + n > c->n_reads) return fail(PPQC_E_INVALID, "read range out of bounds");
     CHK(ppqc_sync(c));
     if (n == 0) return PPQC_OK;
+    uint64_t bad = 0;
+    HIPCHK(hipMemcpy(&bad, c->res_buf + c->res_words, 8, hipMemcpyDeviceToHost));
+    if (bad) return fail(PPQC_E_INVALID, "malformed CSR in a device batch: " + std::to_string(bad) + " rows with bad offsets");
     const ReadArrays& r = c->ra;
 #define D2H(dst, src, T) \
     if (dst) HIPCHK(hipMemcpy(dst, (src) + first, n * sizeof(T), hipMemcpyDeviceToHost))
@@ -586,9 +593,11 @@ int ppqc_fetch_tables(ppqc_ctx* c, ppqc_tables* o) {
     if (c->state < 3) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes/tables/n50 first");
     CHK(ppqc_sync(c));
     const TableLayout& l = c->tp.lay;
-    HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, c->res_words * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, (c->res_words + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     const uint64_t* h = c->res_host;
+    if (h[c->res_words])
+        return fail(PPQC_E_INVALID, "malformed CSR in a device batch: " + std::to_string(h[c->res_words]) + " rows with bad offsets");
     const uint64_t nch = l.n_channels, nb = l.n_time_bins, cells = nch * l.n_mux * nb;
 #define OUT(dst, off, cnt) if (dst) memcpy(dst, h + (off), (cnt) * 8)
     OUT(o->totals, l.off_totals, PPQC_N_TOTALS); OUT(o->len_hist_log2, l.off_len_log2, PPQC_N_LEN_LOG2);

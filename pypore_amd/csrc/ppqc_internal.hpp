@@ -77,7 +77,8 @@ struct TableParams {
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
                               Partial* head, Partial* tail, int n_cu, hipStream_t s);
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
-                                 const Partial* tail, uint64_t thr_fail, double fail_q, hipStream_t s);
+                                 const Partial* tail, uint64_t thr_fail, double fail_q, uint64_t* csr_errors,
+                                 hipStream_t s);
 
 // Pre-computed reads (sequencing_summary.txt rows): device arrays of n entries appended at read_base.
 hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const uint32_t* len, const double* mean_q,

@@ -283,10 +283,16 @@ __global__ __launch_bounds__(256) void tile_kernel(BatchView b, const uint64_t* 
 __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadArrays ra, uint64_t read_base,
                                                              const Partial* __restrict__ head,
                                                              const Partial* __restrict__ tail, uint64_t thr_fail,
-                                                             double fail_q) {
+                                                             double fail_q, uint64_t* __restrict__ csr_errors) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.n_reads) return;
-    const uint64_t a = b.offsets[i], e = b.offsets[i + 1];
+    uint64_t a = b.offsets[i], e = b.offsets[i + 1];
+    // A device batch cannot be validated on the host: a malformed CSR must neither fault (the partial arrays are
+    // indexed by tile) nor pass silently -- the read is zeroed and counted; ppqc_fetch_tables / ppqc_read_stats fail.
+    if (e < a || e > b.n_bytes || e - a >= 0xFFFFFFFFull || (i == 0 && a != 0) || (i + 1 == b.n_reads && e != b.n_bytes)) {
+        atomicAdd((unsigned long long*)csr_errors, 1ull);
+        a = e = 0;
+    }
     const uint64_t L = e - a, g = read_base + i;
     uint64_t gcs = 0, nn = 0, qb = 0, hi = 0, lo = 0;
     if (L != 0) {
@@ -372,11 +378,12 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
 }
 
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
-                                 const Partial* tail, uint64_t thr_fail, double fail_q, hipStream_t s) {
+                                 const Partial* tail, uint64_t thr_fail, double fail_q, uint64_t* csr_errors,
+                                 hipStream_t s) {
     if (b.n_reads == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((b.n_reads + 255) / 256);
     hipLaunchKernelGGL(finalize_reads_kernel, dim3(blocks), dim3(256), 0, s, b, ra, read_base, head, tail, thr_fail,
-                       fail_q);
+                       fail_q, csr_errors);
     return hipGetLastError();
 }
 

@@ -355,3 +355,29 @@ def test_n50_radix_select_equals_sort(qc, c_oracle):
             b = ctx.fetch_tables()
         assert a["n50"] == b["n50"] == c_oracle.n50(lens), (lens[:8], a["n50"], b["n50"])
         assert_tables_equal(a, b)
+
+
+def test_malformed_device_csr_fails_loudly_without_faulting(qc):
+    """A device batch cannot be validated on the host; bad offsets must neither fault nor pass."""
+    import torch
+    from pypore_amd._lib import PPQCError
+    nb = 200_000
+    tb = torch.full((nb + 64,), ord("G"), dtype=torch.uint8, device="cuda")
+    tq = torch.full((nb + 64,), 60, dtype=torch.uint8, device="cuda")
+    meta = [torch.ones(4, dtype=torch.int32, device="cuda"), torch.ones(4, dtype=torch.uint8, device="cuda"),
+            torch.full((4,), 1_528_000_000, dtype=torch.int64, device="cuda")]
+    for offs in ([0, 100_000, 50_000, 150_000, nb],          # not monotone
+                 [0, 10, 20, 30, nb + (1 << 40)],              # runs far past the data
+                 [16, 100, 200, 300, nb]):                     # does not start at 0
+        with qc.QCContext(device=0, **BASE_CFG) as ctx:
+            d_off = torch.tensor(offs, dtype=torch.int64, device="cuda")
+            ctx.submit_device(4, nb, tb.data_ptr(), tq.data_ptr(), d_off.data_ptr(), *[m.data_ptr() for m in meta])
+            with pytest.raises(PPQCError, match="malformed CSR"):
+                ctx.read_stats()
+            with pytest.raises(PPQCError, match="malformed CSR"):
+                ctx.finalize()
+            ctx.reset()                                        # the context stays usable
+            good = torch.tensor([0, 10, 20, 30, nb], dtype=torch.int64, device="cuda")
+            ctx.submit_device(4, nb, tb.data_ptr(), tq.data_ptr(), good.data_ptr(), *[m.data_ptr() for m in meta])
+            t = ctx.finalize()
+            assert int(t["totals"][1]) == nb and int(t["totals"][3]) == nb
