@@ -199,6 +199,18 @@ int ppqc_submit(ppqc_ctx* ctx, const ppqc_batch* host_batch, int slot);
 int ppqc_submit_device(ppqc_ctx* ctx, const ppqc_batch* device_batch);
 /* Replaces the per-row work of summary_reader (lib/seq_routines.py:838-842, :852-855): appends pre-computed reads. */
 int ppqc_submit_records(ppqc_ctx* ctx, const ppqc_records* host_records);
+/* FASTQ text straight to per-read statistics, tokenised on the GPU (no host parsing at all): replaces
+ * SeqIO.parse(handle, "fastq") + GC() of fastq_reader (lib/seq_routines.py:47-53) for a whole file (or any text that
+ * consists of complete records).  Strict 4-line records ("\n" or "\r\n"); channel and start time come from the
+ * albacore header fields ch= / start_time= (0 / INT64_MIN if absent, as ppqc_fastq_pack), every read gets `mux`.
+ * The number of records appended is returned in *n_records.  Malformed records (no '@', no '+', differing captions,
+ * sequence and quality lengths differ) are detected on the device: the call itself fails if the line count is not a
+ * multiple of 4, otherwise ppqc_fetch_tables / ppqc_read_stats fail with the first bad record's number.  Not checked
+ * here (SeqIO would raise; ppqc_fastq_scan/pack do check): blanks inside a sequence line, quality bytes outside
+ * '!'..'~' (clamped as in ppqc_submit).  The host variant copies through staging slot 0|1 like ppqc_submit; the
+ * device variant needs a 16-byte aligned pointer. */
+int ppqc_submit_fastq(ppqc_ctx* ctx, const uint8_t* host_text, uint64_t n, int slot, uint8_t mux, uint64_t* n_records);
+int ppqc_submit_fastq_device(ppqc_ctx* ctx, const uint8_t* device_text, uint64_t n, uint8_t mux, uint64_t* n_records);
 int ppqc_sync(ppqc_ctx* ctx);
 
 int ppqc_n_reads(ppqc_ctx* ctx, uint64_t* n);

@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ["ppqc_api.hip", "ppqc_tile.hip", "ppqc_tables.hip", "ppqc_sort.hip", "ppqc_synth.hip", "ppqc_fastq.cpp"]
+SRC = ["ppqc_api.hip", "ppqc_tile.hip", "ppqc_tables.hip", "ppqc_sort.hip", "ppqc_synth.hip", "ppqc_fastq_gpu.hip", "ppqc_fastq.cpp"]
 OUT = os.path.join(HERE, "libpypore_qc.so")
 
 

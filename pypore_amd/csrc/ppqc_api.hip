@@ -78,6 +78,11 @@ struct ppqc_ctx {
     uint32_t *chan_start = nullptr, *first_desc = nullptr;
     uint64_t cap_sort32 = 0, cap_sort64 = 0;
 
+    // FASTQ-on-GPU scratch
+    FastqScratch fq{};
+    ReadArrays lra{};           // rec_* only: raw sums per text line
+    uint64_t cap_chunks = 0, cap_lines = 0;
+
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr, ev_max = nullptr;
@@ -156,6 +161,15 @@ static int ensure_sort64(ppqc_ctx* c, uint64_t n) {
     CHK(grow(&c->vals, 0, cap, c->stream));
     CHK(grow(&c->vals_tmp, 0, cap, c->stream));
     c->cap_sort64 = cap;
+    return PPQC_OK;
+}
+
+static int input_errors(const uint64_t* e) {
+    if (e[0]) return fail(PPQC_E_INVALID, "malformed CSR in a device batch: " + std::to_string(e[0]) + " rows with bad offsets");
+    if (e[1])
+        return fail(PPQC_E_INVALID, "malformed FASTQ: " + std::to_string(e[1]) + " bad records, the first is record " +
+                                        std::to_string(e[2]) + " of its text (header without '@', third line without '+', "
+                                        "differing captions, or sequence and quality lengths differ)");
     return PPQC_OK;
 }
 
@@ -261,9 +275,11 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     const uint64_t nch1 = 1 + (uint64_t)cfg->n_channels;
     c->res_words = tp.lay.n_sum + PPQC_N_SEL + 2 * nch1 + 8;
     // one extra word behind the results: the count of malformed device-CSR rows (never touched by init_results)
-    HIPCHK(hipMalloc((void**)&c->res_buf, (c->res_words + 1) * 8));
-    HIPCHK(hipMemset(c->res_buf + c->res_words, 0, 8));
-    HIPCHK(hipHostMalloc((void**)&c->res_host, (c->res_words + 1) * 8, hipHostMallocDefault));
+    //  [0] malformed device-CSR rows, [1] malformed FASTQ records, [2] number of the first of those
+    HIPCHK(hipMalloc((void**)&c->res_buf, (c->res_words + 3) * 8));
+    HIPCHK(hipMemset(c->res_buf + c->res_words, 0, 16));
+    HIPCHK(hipMemset(c->res_buf + c->res_words + 2, 0xFF, 8));
+    HIPCHK(hipHostMalloc((void**)&c->res_host, (c->res_words + 3) * 8, hipHostMallocDefault));
     c->sum_buf = c->res_buf;
     c->sel_buf = c->sum_buf + tp.lay.n_sum;
     c->max_buf = c->sel_buf + PPQC_N_SEL;
@@ -285,7 +301,8 @@ int ppqc_destroy(ppqc_ctx* c) {
     ReadArrays& r = c->ra;
     void* ptrs[] = {r.rec_cnt, r.rec_hi, r.rec_lo, r.len, r.gc, r.nn, r.qsum, r.mean_q, r.err_hi, r.err_lo, r.flags,
                     r.channel, r.mux, r.time, r.hour, r.lens32, c->head, c->tail, c->res_buf, c->sk32, c->sk32_tmp, c->counts, c->vals, c->vals_tmp, c->sk64,
-                    c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev};
+                    c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev, c->fq.counts, c->fq.prefix,
+                    c->fq.block_sums, c->fq.line_off, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->maxlen_host) (void)hipHostFree(c->maxlen_host);
@@ -311,7 +328,8 @@ int ppqc_reset(ppqc_ctx* c) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemsetAsync(c->res_buf + c->res_words, 0, 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->res_buf + c->res_words, 0, 16, c->stream));
+    HIPCHK(hipMemsetAsync(c->res_buf + c->res_words + 2, 0xFF, 8, c->stream));
     c->n_reads = 0;
     c->state = 0;
     c->n50 = 0;
@@ -427,6 +445,82 @@ int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
     return PPQC_OK;
 }
 
+// FASTQ text resident in device memory -> per-read arrays (see ppqc_fastq_gpu.hip).  One host synchronisation: the
+// number of lines has to be known to size the line table and the per-read arrays.
+static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, uint64_t* n_records) {
+    if (n_records) *n_records = 0;
+    if (n == 0) return PPQC_OK;
+    hipStream_t s = c->stream;
+    const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
+    if (n_chunks > c->cap_chunks) {
+        const uint64_t cap = n_chunks + n_chunks / 4 + 64;
+        CHK(grow(&c->fq.counts, 0, cap, s)); CHK(grow(&c->fq.prefix, 0, cap + 1, s));
+        CHK(grow(&c->fq.block_sums, 0, nl_scan_block_words(cap), s));
+        c->cap_chunks = cap;
+    }
+    HIPCHK(launch_nl_count_scan(text, n, c->fq, s));
+    uint64_t* h = c->maxlen_host;   // pinned scratch words [1] = newlines, [2] = last byte
+    h[2] = 0;
+    HIPCHK(hipMemcpyAsync(&h[1], c->fq.prefix + n_chunks, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&h[2], text + n - 1, 1, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const uint64_t n_lines = h[1] + (((uint8_t)h[2]) != '\n' ? 1 : 0);
+    if (n_lines % 4 != 0)
+        return fail(PPQC_E_INVALID, "FASTQ text has " + std::to_string(n_lines) + " lines, not a multiple of 4 (blank "
+                                        "lines or multi-line records: use ppqc_fastq_scan / ppqc_fastq_pack)");
+    const uint64_t R = n_lines / 4;
+    if (R >= (1ull << 30)) return fail(PPQC_E_RANGE, "more than 2^30-1 records in one text");
+    if (n_lines > c->cap_lines) {
+        const uint64_t cap = n_lines + n_lines / 4 + 64;
+        CHK(grow(&c->fq.line_off, 0, cap + 1, s));
+        CHK(grow(&c->lra.rec_cnt, 0, cap, s)); CHK(grow(&c->lra.rec_hi, 0, cap, s)); CHK(grow(&c->lra.rec_lo, 0, cap, s));
+        c->cap_lines = cap;
+    }
+    CHK(ensure_reads(c, c->n_reads + R));
+    const uint32_t shift = kDefaultTileShift;
+    CHK(ensure_tiles(c, (n + (1ull << shift) - 1) >> shift));
+    HIPCHK(launch_nl_fill(text, n, n_lines, c->fq, s));
+    // line mode: both classifiers run over the same text, every line is a segment
+    BatchView v{text, text, c->fq.line_off, n_lines, n, nullptr, shift, nullptr, nullptr, nullptr};
+    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->n_cu, s));
+    HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
+                                 c->lut_dev, c->tp.thr_fail, c->tp.fail_q, mux, c->res_buf + c->res_words, s));
+    c->n_reads += R;
+    c->state = 0;
+    if (n_records) *n_records = R;
+    return PPQC_OK;
+}
+
+int ppqc_submit_fastq_device(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, uint64_t* n_records) {
+    if (!c || (!text && n)) return fail(PPQC_E_INVALID, "null argument");
+    if ((uintptr_t)text & 15) return fail(PPQC_E_INVALID, "device text must be 16-byte aligned");
+    HIPCHK(hipSetDevice(c->device));
+    return run_fastq(c, text, n, mux, n_records);
+}
+
+int ppqc_submit_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, int si, uint8_t mux, uint64_t* n_records) {
+    if (!c || (!text && n)) return fail(PPQC_E_INVALID, "null argument");
+    if (si < 0 || si > 1) return fail(PPQC_E_INVALID, "slot must be 0 or 1");
+    if (n_records) *n_records = 0;
+    if (n == 0) return PPQC_OK;
+    HIPCHK(hipSetDevice(c->device));
+    Slot& s = c->slot[si];
+    if (s.busy) { HIPCHK(hipEventSynchronize(s.done)); s.busy = false; }
+    if (n > s.cap_bytes) {
+        const uint64_t cap = n + n / 4 + 4096;
+        CHK(slot_grow(&s.bases, cap)); CHK(slot_grow(&s.quals, cap));
+        s.cap_bytes = cap;
+    }
+    hipStream_t cs = c->copy[si];
+    HIPCHK(hipMemcpyAsync(s.bases, text, n, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipEventRecord(s.copied, cs));
+    HIPCHK(hipStreamWaitEvent(c->stream, s.copied, 0));
+    CHK(run_fastq(c, s.bases, n, mux, n_records));
+    HIPCHK(hipEventRecord(s.done, c->stream));
+    s.busy = true;
+    return PPQC_OK;
+}
+
 int ppqc_submit_records(ppqc_ctx* c, const ppqc_records* r) {
     if (!c || !r) return fail(PPQC_E_INVALID, "null argument");
     const uint64_t n = r->n_reads;
@@ -491,9 +585,9 @@ int ppqc_read_stats(ppqc_ctx* c, const ppqc_per_read* o, uint64_t first, uint64_
     if (first + n > c->n_reads) return fail(PPQC_E_INVALID, "read range out of bounds");
     CHK(ppqc_sync(c));
     if (n == 0) return PPQC_OK;
-    uint64_t bad = 0;
-    HIPCHK(hipMemcpy(&bad, c->res_buf + c->res_words, 8, hipMemcpyDeviceToHost));
-    if (bad) return fail(PPQC_E_INVALID, "malformed CSR in a device batch: " + std::to_string(bad) + " rows with bad offsets");
+    uint64_t bad[3] = {0, 0, 0};
+    HIPCHK(hipMemcpy(bad, c->res_buf + c->res_words, 24, hipMemcpyDeviceToHost));
+    CHK(input_errors(bad));
     const ReadArrays& r = c->ra;
 #define D2H(dst, src, T) \
     if (dst) HIPCHK(hipMemcpy(dst, (src) + first, n * sizeof(T), hipMemcpyDeviceToHost))
@@ -593,11 +687,10 @@ int ppqc_fetch_tables(ppqc_ctx* c, ppqc_tables* o) {
     if (c->state < 3) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes/tables/n50 first");
     CHK(ppqc_sync(c));
     const TableLayout& l = c->tp.lay;
-    HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, (c->res_words + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, (c->res_words + 3) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     const uint64_t* h = c->res_host;
-    if (h[c->res_words])
-        return fail(PPQC_E_INVALID, "malformed CSR in a device batch: " + std::to_string(h[c->res_words]) + " rows with bad offsets");
+    CHK(input_errors(h + c->res_words));
     const uint64_t nch = l.n_channels, nb = l.n_time_bins, cells = nch * l.n_mux * nb;
 #define OUT(dst, off, cnt) if (dst) memcpy(dst, h + (off), (cnt) * 8)
     OUT(o->totals, l.off_totals, PPQC_N_TOTALS); OUT(o->len_hist_log2, l.off_len_log2, PPQC_N_LEN_LOG2);

@@ -1,0 +1,311 @@
+// FASTQ text -> per-read statistics without a host tokenizer (gfx950).
+//
+// Replaces, for text that is already in (or on its way to) HBM, the record parsing the reference leaves to Biopython
+// (SeqIO.parse(handle, "fastq"), lib/seq_routines.py:50; record layout lib/fast5_reader.py:57, lib/fastqparser.py:7-16).
+// Strict 4-line records only; anything else is counted as malformed and the run fails loudly (the host packer
+// ppqc_fastq_scan/pack accepts blank lines between records and reports the record number).
+//
+// The text is never compacted into separate base / quality streams.  Instead:
+//   1. nl_count + scan + nl_fill build the table of line starts (two streaming passes over the text);
+//   2. the per-read tile kernel runs in "line mode": bases = quals = text, offsets = line starts, so every LINE gets
+//      the raw sums of both classifiers (G/C/S and N counts, quality byte sum, fixed-point error sum);
+//   3. fastq_finalize (one thread per record) takes the base sums of line 2 and the quality sums of line 4, removes
+//      the contribution of the stripped line end from the quality sums, validates the record and writes the same
+//      per-read arrays finalize_reads writes.
+// Traffic: about 3 reads of the text (2.05 bytes per base each) and no write of the sequence bytes.
+#include "ppqc_internal.hpp"
+
+namespace ppqc {
+
+// high bit of each byte set where the byte equals '\n' (exact zero-byte detector on v ^ 0x0A..)
+__device__ __forceinline__ uint32_t nl_mask(uint32_t v) {
+    const uint32_t x = v ^ 0x0A0A0A0Au;
+    const uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu;
+    return ~t;
+}
+
+// 16-bit mask (bit k = byte k of the lane's 16-byte vector is a newline), bytes at or beyond `valid` cleared
+__device__ __forceinline__ uint32_t vec_nl_bits(const uint4& v, int valid) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t m = nl_mask(w[k]);
+        bits |= (((m >> 7) & 1u) | ((m >> 14) & 2u) | ((m >> 21) & 4u) | ((m >> 28) & 8u)) << (4 * k);
+    }
+    if (valid < 16) bits &= valid <= 0 ? 0u : ((1u << valid) - 1u);
+    return bits;
+}
+
+__device__ __forceinline__ uint4 load_vec_clamped(const uint8_t* __restrict__ text, uint64_t pos, uint64_t n) {
+    // 16-byte aligned load; a vector that starts beyond the data is replaced by the last in-bounds one (masked later)
+    const uint64_t last = (n - 1) & ~15ull;
+    return *reinterpret_cast<const uint4*>(text + (pos < last ? pos : last));
+}
+
+// one wave per chunk of kNlChunk bytes
+__global__ __launch_bounds__(256) void nl_count_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                       uint32_t* __restrict__ counts, uint64_t n_chunks) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (chunk >= n_chunks) return;
+    uint32_t c = 0;
+#pragma unroll
+    for (int it = 0; it < (int)(kNlChunk / kSpan); ++it) {
+        const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
+        if (pos < n) {
+            const uint4 v = load_vec_clamped(text, pos, n);
+            const uint64_t rem = n - pos;
+            c += __popc(vec_nl_bits(v, rem < 16 ? (int)rem : 16));
+        }
+    }
+    c = (uint32_t)wave_sum_u64(c);
+    if (lane == 0) counts[chunk] = c;
+}
+
+constexpr int kScanBlock = 2048;   // entries per block of the two-level scan
+uint64_t nl_scan_block_words(uint64_t n_chunks) { return (n_chunks + kScanBlock - 1) / kScanBlock + 2; }
+
+__global__ __launch_bounds__(256) void nl_blocksum_kernel(const uint32_t* __restrict__ counts, uint64_t n,
+                                                          uint64_t* __restrict__ bsum) {
+    __shared__ unsigned long long acc;
+    if (threadIdx.x == 0) acc = 0;
+    __syncthreads();
+    uint64_t t = 0;
+    for (int k = 0; k < kScanBlock / 256; ++k) {
+        const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)k * 256 + threadIdx.x;
+        if (i < n) t += counts[i];
+    }
+    t = wave_sum_u64(t);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&acc, (unsigned long long)t);
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = acc;
+}
+
+// single block: exclusive scan of the block sums in place; grand total -> *total
+__global__ __launch_bounds__(256) void nl_scan_top_kernel(uint64_t* __restrict__ bsum, uint64_t nblocks,
+                                                          uint64_t* __restrict__ total) {
+    __shared__ uint64_t part[256];
+    const uint32_t t = threadIdx.x;
+    const uint64_t seg = (nblocks + 255) / 256;
+    const uint64_t b = t * seg, e = b + seg < nblocks ? b + seg : nblocks;
+    uint64_t s = 0;
+    for (uint64_t i = b; i < e; ++i) s += bsum[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 256; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    uint64_t run = part[t];
+    for (uint64_t i = b; i < e; ++i) { const uint64_t v = bsum[i]; bsum[i] = run; run += v; }
+}
+
+// per block of kScanBlock entries: thread owns 8 consecutive entries
+__global__ __launch_bounds__(256) void nl_scan_apply_kernel(const uint32_t* __restrict__ counts, uint64_t n,
+                                                            const uint64_t* __restrict__ bsum,
+                                                            uint64_t* __restrict__ prefix) {
+    __shared__ uint64_t part[256];
+    const uint32_t t = threadIdx.x;
+    const uint64_t b0 = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)t * 8;
+    uint32_t v[8];
+    uint64_t loc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = b0 + k < n ? counts[b0 + k] : 0; loc += v[k]; }
+    part[t] = loc;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t run = bsum[blockIdx.x];
+        for (int i = 0; i < 256; ++i) { const uint64_t x = part[i]; part[i] = run; run += x; }
+    }
+    __syncthreads();
+    uint64_t run = part[t];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (b0 + k < n) prefix[b0 + k] = run;
+        run += v[k];
+    }
+}
+
+hipError_t launch_nl_count_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, hipStream_t s) {
+    const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
+    if (n_chunks == 0) return hipMemsetAsync(fs.prefix, 0, 8, s);
+    hipLaunchKernelGGL(nl_count_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, text, n, fs.counts, n_chunks);
+    const uint64_t nblocks = (n_chunks + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(nl_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, fs.counts, n_chunks, fs.block_sums);
+    hipLaunchKernelGGL(nl_scan_top_kernel, dim3(1), dim3(256), 0, s, fs.block_sums, nblocks, fs.prefix + n_chunks);
+    hipLaunchKernelGGL(nl_scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, fs.counts, n_chunks,
+                       fs.block_sums, fs.prefix);
+    return hipGetLastError();
+}
+
+// one wave per chunk again: the k-th newline of the text (0-based) at byte p sets line_off[k + 1] = p + 1
+__global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                      const uint64_t* __restrict__ prefix, uint64_t n_chunks,
+                                                      uint64_t* __restrict__ line_off, uint64_t n_lines) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { line_off[0] = 0; line_off[n_lines] = n; }
+    if (chunk >= n_chunks) return;
+    uint64_t base = uniform_u64(prefix[chunk]);
+    for (int it = 0; it < (int)(kNlChunk / kSpan); ++it) {
+        const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
+        uint32_t bits = 0;
+        if (pos < n) {
+            const uint4 v = load_vec_clamped(text, pos, n);
+            const uint64_t rem = n - pos;
+            bits = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
+        }
+        const uint32_t cnt = __popc(bits);
+        uint32_t inc = cnt;   // inclusive wave prefix of the lane counts
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        uint64_t k = base + (inc - cnt);
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            if (k + 1 < n_lines) line_off[k + 1] = pos + (uint64_t)b + 1;   // a final newline at n - 1 is line_off[n_lines] = n
+            ++k;
+        }
+        base += (uint32_t)__shfl((int)inc, 63);
+    }
+}
+
+hipError_t launch_nl_fill(const uint8_t* text, uint64_t n, uint64_t n_lines, const FastqScratch& fs, hipStream_t s) {
+    const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
+    const uint64_t blocks = n_chunks ? (n_chunks + 3) / 4 : 1;
+    hipLaunchKernelGGL(nl_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, text, n, fs.prefix, n_chunks, fs.line_off,
+                       n_lines);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ bool is_space(uint8_t c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+
+// " key=" at the start of the header or after a blank: returns the position after the key, or e if absent
+__device__ inline uint64_t find_field(const uint8_t* __restrict__ t, uint64_t a, uint64_t e, const char* key, int klen) {
+    for (uint64_t i = a; i + klen <= e; ++i) {
+        if (i != a && t[i - 1] != ' ' && t[i - 1] != '\t') continue;
+        bool ok = true;
+        for (int k = 0; k < klen && ok; ++k) ok = t[i + k] == (uint8_t)key[k];
+        if (ok) return i + klen;
+    }
+    return e;
+}
+
+__device__ inline int64_t days_from_civil(int64_t y, unsigned m, unsigned d) {
+    y -= m <= 2;
+    const int64_t era = (y >= 0 ? y : y - 399) / 400;
+    const unsigned yoe = (unsigned)(y - era * 400);
+    const unsigned doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+    const unsigned doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+    return era * 146097 + (int64_t)doe - 719468;
+}
+
+// "YYYY-MM-DDTHH:MM:SS" at t[p..e): seconds since the epoch (UTC), INT64_MIN if it does not parse
+__device__ inline int64_t parse_iso8601(const uint8_t* __restrict__ t, uint64_t p, uint64_t e) {
+    if (e - p < 19) return INT64_MIN;
+    int64_t f[6];
+    const int beg[6] = {0, 5, 8, 11, 14, 17}, end[6] = {4, 7, 10, 13, 16, 19};
+    for (int k = 0; k < 6; ++k) {
+        int64_t x = 0;
+        for (int i = beg[k]; i < end[k]; ++i) {
+            const uint8_t c = t[p + i];
+            if (c < '0' || c > '9') return INT64_MIN;
+            x = x * 10 + (c - '0');
+        }
+        f[k] = x;
+    }
+    if (t[p + 4] != '-' || t[p + 7] != '-' || (t[p + 10] != 'T' && t[p + 10] != ' ') || t[p + 13] != ':' || t[p + 16] != ':')
+        return INT64_MIN;
+    if (f[1] < 1 || f[1] > 12 || f[2] < 1 || f[2] > 31) return INT64_MIN;
+    return days_from_civil(f[0], (unsigned)f[1], (unsigned)f[2]) * 86400 + f[3] * 3600 + f[4] * 60 + f[5];
+}
+
+__global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                             uint64_t n_records, const uint64_t* __restrict__ lo,
+                                                             ReadArrays lra, ReadArrays ra, uint64_t read_base,
+                                                             const Partial* __restrict__ head,
+                                                             const Partial* __restrict__ tail, uint32_t tile_shift,
+                                                             const uint64_t* __restrict__ lut, uint64_t thr_fail,
+                                                             double fail_q, uint8_t mux, uint64_t* __restrict__ errors) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_records) return;
+    const uint64_t g = read_base + r;
+    uint64_t a[4], e[4];
+    uint64_t strip_qb = 0, strip_err = 0;   // what the stripped end of the quality line added to its raw sums
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = lo[4 * r + k];
+        e[k] = lo[4 * r + k + 1];
+        while (e[k] > a[k] && is_space(text[e[k] - 1])) {   // '\n', "\r\n", trailing blanks: what rstrip() removes
+            --e[k];
+            if (k == 3) { strip_qb += text[e[k]]; strip_err += lut[text[e[k]]]; }
+        }
+    }
+    const uint64_t L = e[1] - a[1];
+    bool ok = e[0] > a[0] && text[a[0]] == '@' && e[2] > a[2] && text[a[2]] == '+' && L == e[3] - a[3] && L < 0xFFFFFFFFull;
+    if (ok && e[2] - a[2] > 1) {   // an optional repeated title must match (SeqIO: "captions differ")
+        ok = e[2] - a[2] == e[0] - a[0];
+        for (uint64_t i = 1; ok && i < e[2] - a[2]; ++i) ok = text[a[2] + i] == text[a[0] + i];
+    }
+    uint64_t gcs = 0, nn = 0, qb = 0, hi = 0, lw = 0;
+    if (!ok) {
+        atomicAdd((unsigned long long*)&errors[1], 1ull);
+        atomicMin((unsigned long long*)&errors[2], (unsigned long long)r);
+    } else if (L != 0) {
+        const uint64_t s1 = lo[4 * r + 1], f1 = lo[4 * r + 2], s3 = lo[4 * r + 3], f3 = lo[4 * r + 4];
+        const SegSums b = merged_sums(s1, f1, 4 * r + 1, lra, head, tail, tile_shift);
+        const SegSums q = merged_sums(s3, f3, 4 * r + 3, lra, head, tail, tile_shift);
+        gcs = b.gcs; nn = b.nn;
+        qb = q.qb - strip_qb;
+        // S = hi * 2^32 + lo with halves that are sums; subtract the stripped bytes from the combined value
+        const unsigned __int128 S = (((unsigned __int128)q.hi) << 32) + q.lo - strip_err;
+        hi = (uint64_t)(S >> 32); lw = (uint64_t)S & 0xffffffffull;
+    }
+    const uint64_t Lr = ok ? L : 0;
+    uint8_t flags = 0;
+    double mq = 0.0;
+    if (Lr != 0) {
+        const double S = (double)hi * 4294967296.0 + (double)lw;
+        mq = -10.0 * log10(S / ((double)Lr * 4503599627370496.0));
+        const unsigned __int128 S128 = ((unsigned __int128)hi << 32) + lw;
+        flags = S128 > (unsigned __int128)Lr * thr_fail ? 1 : 0;
+    } else {
+        flags = 0.0 < fail_q ? 1 : 0;
+    }
+    ra.len[g] = (uint32_t)Lr; ra.gc[g] = (uint32_t)gcs; ra.nn[g] = (uint32_t)nn;
+    ra.qsum[g] = (int64_t)qb - 33 * (int64_t)Lr;
+    ra.err_hi[g] = hi; ra.err_lo[g] = lw;
+    ra.mean_q[g] = mq;
+    ra.flags[g] = flags;
+    // albacore header fields (the reference reads ch= at lib/seq_routines.py:51)
+    uint32_t ch = 0;
+    int64_t tm = INT64_MIN;
+    if (ok) {
+        uint64_t p = find_field(text, a[0] + 1, e[0], "ch=", 3);
+        for (; p < e[0] && text[p] >= '0' && text[p] <= '9'; ++p) ch = ch * 10 + (uint32_t)(text[p] - '0');
+        p = find_field(text, a[0] + 1, e[0], "start_time=", 11);
+        if (p < e[0]) tm = parse_iso8601(text, p, e[0]);
+    }
+    ra.channel[g] = ch;
+    ra.mux[g] = mux;
+    ra.time[g] = tm;
+}
+
+hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
+                                 ReadArrays line_ra, ReadArrays ra, uint64_t read_base, const Partial* head,
+                                 const Partial* tail, uint32_t tile_shift, const uint64_t* lut, uint64_t thr_fail,
+                                 double fail_q, uint8_t mux, uint64_t* errors, hipStream_t s) {
+    if (n_records == 0) return hipSuccess;
+    hipLaunchKernelGGL(fastq_finalize_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n,
+                       n_records, line_off, line_ra, ra, read_base, head, tail, tile_shift, lut, thr_fail, fail_q, mux,
+                       errors);
+    return hipGetLastError();
+}
+
+}  // namespace ppqc

@@ -122,6 +122,26 @@ hipError_t launch_select_hist(const uint32_t* lens, uint64_t n, int shift, int n
 hipError_t launch_select_pick(uint64_t* sel, const uint64_t* total, uint64_t* state, int shift, int nbits, bool last,
                               uint64_t* out, hipStream_t s);
 
+// ---- FASTQ text on the GPU (ppqc_fastq_gpu.hip) --------------------------------------------------------------------
+constexpr uint32_t kNlChunk = 4096;   // bytes of text per newline-count entry (one wave, four 1 KiB spans)
+struct FastqScratch {
+    uint32_t* counts;       // newlines per chunk
+    uint64_t* prefix;       // exclusive prefix of counts; prefix[n_chunks] = total
+    uint64_t* block_sums;   // scan scratch
+    uint64_t* line_off;     // n_lines + 1 line starts (the CSR offsets of the line-mode tile kernel)
+};
+uint64_t nl_scan_block_words(uint64_t n_chunks);
+// counts newlines per chunk and scans them; the total lands in fs.prefix[n_chunks]
+hipError_t launch_nl_count_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, hipStream_t s);
+// line_off[0] = 0, line_off[k + 1] = position after the k-th newline, line_off[n_lines] = n
+hipError_t launch_nl_fill(const uint8_t* text, uint64_t n, uint64_t n_lines, const FastqScratch& fs, hipStream_t s);
+// one thread per record: validates the four lines, strips line ends, merges the line sums into the per-read arrays,
+// parses ch= and start_time= out of the header.  errors[1] counts malformed records.
+hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
+                                 ReadArrays line_ra, ReadArrays ra, uint64_t read_base, const Partial* head,
+                                 const Partial* tail, uint32_t tile_shift, const uint64_t* lut, uint64_t thr_fail,
+                                 double fail_q, uint8_t mux, uint64_t* errors, hipStream_t s);
+
 hipError_t launch_synth(uint8_t* bases, uint8_t* quals, uint64_t first, uint64_t n, uint64_t seed, hipStream_t s);
 
 // ---- device helpers ----------------------------------------------------------------------------------------------
@@ -147,6 +167,28 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
         t += ((uint64_t)h << 32) | l;
     }
     return t;
+}
+// Raw sums of the segment [a, e) of the byte streams (e > a) whose record index is g: complete in rec_* when it lies
+// in one tile, else the tail partial of its first tile plus the head partials of the following ones, in tile order.
+struct SegSums { uint64_t gcs, nn, qb, hi, lo; };
+__device__ __forceinline__ SegSums merged_sums(uint64_t a, uint64_t e, uint64_t g, const ReadArrays& ra,
+                                               const Partial* __restrict__ head, const Partial* __restrict__ tail,
+                                               uint32_t tile_shift) {
+    SegSums r;
+    const uint64_t ts = a >> tile_shift, te = (e - 1) >> tile_shift;
+    if (ts == te) {
+        const uint64_t c = ra.rec_cnt[g];
+        r.gcs = cnt_gcs(c); r.nn = cnt_n(c); r.qb = cnt_qb(c);
+        r.hi = ra.rec_hi[g]; r.lo = ra.rec_lo[g];
+    } else {
+        Partial p = tail[ts];
+        r.gcs = cnt_gcs(p.cnt); r.nn = cnt_n(p.cnt); r.qb = cnt_qb(p.cnt); r.hi = p.hi; r.lo = p.lo;
+        for (uint64_t t = ts + 1; t <= te; ++t) {
+            p = head[t];
+            r.gcs += cnt_gcs(p.cnt); r.nn += cnt_n(p.cnt); r.qb += cnt_qb(p.cnt); r.hi += p.hi; r.lo += p.lo;
+        }
+    }
+    return r;
 }
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
     uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);

@@ -296,19 +296,8 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
     const uint64_t L = e - a, g = read_base + i;
     uint64_t gcs = 0, nn = 0, qb = 0, hi = 0, lo = 0;
     if (L != 0) {
-        const uint64_t ts = a >> b.tile_shift, te = (e - 1) >> b.tile_shift;
-        if (ts == te) {
-            const uint64_t c = ra.rec_cnt[g];
-            gcs = cnt_gcs(c); nn = cnt_n(c); qb = cnt_qb(c);
-            hi = ra.rec_hi[g]; lo = ra.rec_lo[g];
-        } else {
-            Partial p = tail[ts];
-            gcs = cnt_gcs(p.cnt); nn = cnt_n(p.cnt); qb = cnt_qb(p.cnt); hi = p.hi; lo = p.lo;
-            for (uint64_t t = ts + 1; t <= te; ++t) {
-                p = head[t];
-                gcs += cnt_gcs(p.cnt); nn += cnt_n(p.cnt); qb += cnt_qb(p.cnt); hi += p.hi; lo += p.lo;
-            }
-        }
+        const SegSums m = merged_sums(a, e, g, ra, head, tail, b.tile_shift);
+        gcs = m.gcs; nn = m.nn; qb = m.qb; hi = m.hi; lo = m.lo;
     }
     // canonical split S = H * 2^32 + l32, then one correctly rounded conversion to fp64
     const uint64_t H = hi + (lo >> 32), l32 = lo & 0xffffffffull;

@@ -93,6 +93,21 @@ class QCContext:
                     fail_flag_ptr)
         L.check(self._lib.ppqc_submit_device(self._ctx, C.byref(b)))
 
+    def submit_fastq(self, text, slot=0, mux=1):
+        """FASTQ text (bytes / uint8 array, complete 4-line records) tokenised and reduced on the GPU.  Returns the
+        number of records appended.  Channel / start time come from the ch= / start_time= header fields."""
+        buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
+        n = C.c_uint64()
+        L.check(self._lib.ppqc_submit_fastq(self._ctx, _ptr(buf) if buf.size else None, int(buf.size), int(slot),
+                                            int(mux), C.byref(n)))
+        self._keep[int(slot)] = (buf,)
+        return n.value
+
+    def submit_fastq_device(self, text_ptr, n_bytes, mux=1):
+        n = C.c_uint64()
+        L.check(self._lib.ppqc_submit_fastq_device(self._ctx, text_ptr, int(n_bytes), int(mux), C.byref(n)))
+        return n.value
+
     def submit_records(self, length, mean_q, channel, mux, start_time_s, gc_count=None):
         """Reads whose statistics come from a table (albacore sequencing_summary.txt, lib/seq_routines.py:831-863)."""
         length = np.ascontiguousarray(length, dtype=np.uint32)

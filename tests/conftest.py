@@ -17,3 +17,9 @@ def c_oracle():
     from oracle import c_oracle as co
     co.lib()   # builds oracle/libppqc_oracle.so on first use (gcc only)
     return co
+
+
+@pytest.fixture(scope="session")
+def qc_mod():
+    from pypore_amd import qc
+    return qc

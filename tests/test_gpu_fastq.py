@@ -1,0 +1,130 @@
+"""FASTQ text tokenised on the GPU (ppqc_submit_fastq / ppqc_submit_fastq_device) against the host packer + CSR path
+and the oracle: same per-read records and tables, bit for bit, for LF / CRLF text, with and without a final newline,
+repeated captions, reads longer than a tile, empty reads; malformed text fails loudly."""
+import numpy as np
+import pytest
+
+from util import assert_tables_equal
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=0, tz_offset_s=0,
+           ref_time_s=1_527_984_000, fail_q=7.0)
+ALPH = np.frombuffer(b"ACGTACGTNnacgtSs", np.uint8)
+
+
+def _text(seed, n, crlf=False, trailing=True, plus_title=False, lens=None, fields=True):
+    rng = np.random.default_rng(seed)
+    nl = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(n):
+        L = int(lens[i]) if lens is not None else int(rng.choice([0, 1, 15, 16, 17, 1023, 1024, 1025, int(rng.integers(1, 9000))]))
+        seq = bytes(rng.choice(ALPH, L))
+        qual = bytes(rng.integers(33, 127, L, dtype=np.uint8))
+        sec = int(rng.integers(0, 47 * 3600))
+        title = b"read%d runid=ab read=%d" % (i, i)
+        if fields:
+            title += b" ch=%d start_time=2018-06-%02dT%02d:%02d:%02dZ" % (
+                int(rng.integers(1, 513)), 3 + sec // 86400, (sec // 3600) % 24, (sec // 60) % 60, sec % 60)
+        if i % 5 == 0:
+            title += b"  "                      # trailing blanks are stripped like every line end
+        out.append(b"@" + title + nl + seq + nl + b"+" + (title.rstrip() if plus_title else b"") + nl + qual + nl)
+    t = b"".join(out)
+    return t if trailing else t[:-len(nl)]
+
+
+def _host_path(qc, c_oracle, text):
+    from pypore_amd import fastq_io
+    p = fastq_io.pack_fastq(text)
+    mux = np.ones(p["n_reads"], np.uint8)
+    want = c_oracle.per_read(p["bases"], p["quals"], p["offsets"], nthreads=2)
+    tables = c_oracle.tables(want, p["channel"], mux, p["start_time"], None, CFG)
+    return p, want, tables
+
+
+def _check(got, want):
+    for k in ("length", "gc", "n", "qsum"):
+        assert np.array_equal(got[k], want[k]), k
+    assert [(int(h) << 32) + int(l) for h, l in zip(got["err_hi"], got["err_lo"])] == [int(e) for e in want["err"]]
+    np.testing.assert_allclose(got["mean_q"], want["mean_q"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(crlf=True), dict(trailing=False), dict(crlf=True, trailing=False),
+                                dict(plus_title=True)])
+def test_gpu_tokenizer_equals_host_packer(qc_mod, c_oracle, kw):
+    text = _text(11, 700, **kw)
+    p, want, wt = _host_path(qc_mod, c_oracle, text)
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        assert ctx.submit_fastq(text) == p["n_reads"] == 700
+        got = ctx.read_stats()
+        tables = ctx.finalize()
+    _check(got, want)
+    assert_tables_equal(tables, wt, str(kw))
+
+
+def test_long_reads_many_files_both_slots_and_device_variant(qc_mod, c_oracle):
+    import torch
+    lens = [200_003, 65536, 65537, 0, 131072, 5, 70_000] + [300] * 50
+    texts = [_text(21 + k, len(lens), lens=lens, crlf=bool(k % 2)) for k in range(5)]
+    whole = []
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        for k, t in enumerate(texts):
+            assert ctx.submit_fastq(t, slot=k % 2) == len(lens)
+        got = ctx.read_stats()
+        tables = ctx.finalize()
+        # the same texts, already resident in HBM
+        ctx.reset()
+        keep = []
+        for t in texts:
+            d = torch.from_numpy(np.frombuffer(t, np.uint8).copy()).cuda()
+            pad = torch.zeros(d.numel() + 64, dtype=torch.uint8, device="cuda")
+            pad[: d.numel()] = d
+            keep.append(pad)
+            assert ctx.submit_fastq_device(pad.data_ptr(), d.numel()) == len(lens)
+        got2 = ctx.read_stats()
+        tables2 = ctx.finalize()
+    stats, ch, st = [], [], []
+    for t in texts:
+        p, want, _ = _host_path(qc_mod, c_oracle, t)
+        stats.append(want); ch.append(p["channel"]); st.append(p["start_time"])
+    want = {k: np.concatenate([s[k] for s in stats]) for k in ("length", "gc", "n", "qsum", "mean_q")}
+    want["err"] = [e for s in stats for e in s["err"]]
+    _check(got, want)
+    _check(got2, want)
+    ch, st = np.concatenate(ch), np.concatenate(st)
+    wt = c_oracle.tables(want, ch, np.ones(len(ch), np.uint8), st, None, CFG)
+    assert_tables_equal(tables, wt)
+    assert_tables_equal(tables2, wt)
+
+
+def test_headers_without_fields_and_empty_text(qc_mod):
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        assert ctx.submit_fastq(b"") == 0
+        assert ctx.submit_fastq(_text(3, 40, fields=False)) == 40
+        t = ctx.finalize()
+        assert int(t["totals"][0]) == 40 and int(t["totals"][7]) == 40       # channel 0 = bad channel
+
+
+@pytest.mark.parametrize("bad,where", [
+    (b"@r\nACGT\n+\nII\n", "finalize"),                 # lengths differ
+    (b"r\nACGT\n+\nIIII\n", "finalize"),                # no '@'
+    (b"@r\nACGT\n-\nIIII\n", "finalize"),               # no '+'
+    (b"@r\nACGT\n+other\nIIII\n", "finalize"),          # captions differ
+    (b"@r\nACGT\n+\n", "submit"),                       # truncated: 3 lines
+    (b"@r\nACGT\n+\nIIII\n\n@s\nAC\n+\nII\n", "submit"),  # blank line between records: 9 lines
+])
+def test_malformed_text_fails_loudly(qc_mod, bad, where):
+    from pypore_amd._lib import PPQCError
+    good = _text(5, 10)
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        if where == "submit":
+            with pytest.raises(PPQCError, match="multiple of 4"):
+                ctx.submit_fastq(good + bad)
+        else:
+            ctx.submit_fastq(good + bad)
+            with pytest.raises(PPQCError, match="record 10"):
+                ctx.finalize()
+            with pytest.raises(PPQCError, match="malformed FASTQ"):
+                ctx.read_stats()
+        ctx.reset()
+        assert ctx.submit_fastq(good) == 10 and int(ctx.finalize()["totals"][0]) == 10
