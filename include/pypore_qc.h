@@ -212,6 +212,11 @@ int ppqc_submit_records(ppqc_ctx* ctx, const ppqc_records* host_records);
 int ppqc_submit_fastq(ppqc_ctx* ctx, const uint8_t* host_text, uint64_t n, int slot, uint8_t mux, uint64_t* n_records);
 int ppqc_submit_fastq_device(ppqc_ctx* ctx, const uint8_t* device_text, uint64_t n, uint8_t mux, uint64_t* n_records);
 int ppqc_sync(ppqc_ctx* ctx);
+/* Input problems found on the device since create / reset: out[0] malformed rows of device CSR batches, out[1]
+ * malformed FASTQ records, out[2] number of the first of those within its text (UINT64_MAX if none), out[3] quality
+ * bytes outside '!'..'~' seen by the GPU tokenizer (reported like n_bad_qual of ppqc_fastq_pack; [0] and [1] also make
+ * ppqc_fetch_tables / ppqc_read_stats fail).  Synchronises. */
+int ppqc_input_errors(ppqc_ctx* ctx, uint64_t* out4);
 
 int ppqc_n_reads(ppqc_ctx* ctx, uint64_t* n);
 /* Per-read records [first, first+n) (the ChrList entries of lib/fast5_reader.py:127, minus the hour). */
@@ -227,6 +232,12 @@ int ppqc_read_hours(ppqc_ctx* ctx, int32_t* out, uint64_t first, uint64_t n);
  *   ppqc_fetch_tables
  * ppqc_finalize runs all four for the single-GPU case. */
 int ppqc_finalize_extremes(ppqc_ctx* ctx);
+/* Smallest and largest start time over the reads with a valid channel (INT64_MAX / INT64_MIN if there is none); valid
+ * after ppqc_finalize_extremes.  With ppqc_set_ref_time it gives RefTime = the earliest start when the caller has no
+ * better one (the albacore branch does exactly this: ref_start = min start, lib/seq_routines.py:840-841).
+ * ppqc_set_ref_time takes effect in the next ppqc_finalize_extremes (time_mode 0) / ppqc_finalize_tables (time_mode 1). */
+int ppqc_time_range(ppqc_ctx* ctx, int64_t* out2);
+int ppqc_set_ref_time(ppqc_ctx* ctx, int64_t ref_time);
 int ppqc_finalize_tables(ppqc_ctx* ctx);
 int ppqc_finalize_n50(ppqc_ctx* ctx, const uint32_t* device_lengths, uint64_t n);
 int ppqc_fetch_tables(ppqc_ctx* ctx, ppqc_tables* out);

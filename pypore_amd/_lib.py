@@ -28,7 +28,7 @@ SYMBOLS = (
     "ppqc_sync", "ppqc_n_reads", "ppqc_read_stats", "ppqc_read_hours", "ppqc_finalize_extremes",
     "ppqc_finalize_tables", "ppqc_finalize_n50", "ppqc_fetch_tables", "ppqc_finalize", "ppqc_device_tables_view",
     "ppqc_timings", "ppqc_reset_timings", "ppqc_sort_u32_device", "ppqc_synth_fill_device", "ppqc_fastq_scan", "ppqc_fastq_pack",
-    "ppqc_submit_fastq", "ppqc_submit_fastq_device", "ppqc_n50_select_hist", "ppqc_n50_select_pick", "ppqc_set_stream",
+    "ppqc_submit_fastq", "ppqc_submit_fastq_device", "ppqc_input_errors", "ppqc_time_range", "ppqc_set_ref_time", "ppqc_n50_select_hist", "ppqc_n50_select_pick", "ppqc_set_stream",
 )
 
 
@@ -133,6 +133,7 @@ def load():
         "ppqc_sort_u32_device": [P, P, C.c_uint64],
         "ppqc_synth_fill_device": [P, P, P, C.c_uint64, C.c_uint64, C.c_uint64],
         "ppqc_submit_fastq": [P, P, C.c_uint64, C.c_int, C.c_uint8, C.POINTER(C.c_uint64)],
+        "ppqc_input_errors": [P, P], "ppqc_time_range": [P, P], "ppqc_set_ref_time": [P, C.c_int64],
         "ppqc_submit_fastq_device": [P, P, C.c_uint64, C.c_uint8, C.POINTER(C.c_uint64)],
         "ppqc_n50_select_hist": [P, C.c_int], "ppqc_n50_select_pick": [P, C.c_int],
         "ppqc_set_stream": [P, P, C.c_int],

@@ -275,11 +275,13 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     const uint64_t nch1 = 1 + (uint64_t)cfg->n_channels;
     c->res_words = tp.lay.n_sum + PPQC_N_SEL + 2 * nch1 + 8;
     // one extra word behind the results: the count of malformed device-CSR rows (never touched by init_results)
-    //  [0] malformed device-CSR rows, [1] malformed FASTQ records, [2] number of the first of those
-    HIPCHK(hipMalloc((void**)&c->res_buf, (c->res_words + 3) * 8));
+    //  [0] malformed device-CSR rows, [1] malformed FASTQ records, [2] number of the first of those,
+    //  [3] invalid quality bytes seen by the GPU tokenizer (reported, not fatal)
+    HIPCHK(hipMalloc((void**)&c->res_buf, (c->res_words + 4) * 8));
     HIPCHK(hipMemset(c->res_buf + c->res_words, 0, 16));
     HIPCHK(hipMemset(c->res_buf + c->res_words + 2, 0xFF, 8));
-    HIPCHK(hipHostMalloc((void**)&c->res_host, (c->res_words + 3) * 8, hipHostMallocDefault));
+    HIPCHK(hipMemset(c->res_buf + c->res_words + 3, 0, 8));
+    HIPCHK(hipHostMalloc((void**)&c->res_host, (c->res_words + 4) * 8, hipHostMallocDefault));
     c->sum_buf = c->res_buf;
     c->sel_buf = c->sum_buf + tp.lay.n_sum;
     c->max_buf = c->sel_buf + PPQC_N_SEL;
@@ -330,6 +332,7 @@ int ppqc_reset(ppqc_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemsetAsync(c->res_buf + c->res_words, 0, 16, c->stream));
     HIPCHK(hipMemsetAsync(c->res_buf + c->res_words + 2, 0xFF, 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->res_buf + c->res_words + 3, 0, 8, c->stream));
     c->n_reads = 0;
     c->state = 0;
     c->n50 = 0;
@@ -479,7 +482,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     CHK(ensure_reads(c, c->n_reads + R));
     const uint32_t shift = kDefaultTileShift;
     CHK(ensure_tiles(c, (n + (1ull << shift) - 1) >> shift));
-    HIPCHK(launch_nl_fill(text, n, n_lines, c->fq, s));
+    HIPCHK(launch_nl_fill(text, n, n_lines, c->fq, c->res_buf + c->res_words, s));
     // line mode: both classifiers run over the same text, every line is a segment
     BatchView v{text, text, c->fq.line_off, n_lines, n, nullptr, shift, nullptr, nullptr, nullptr};
     HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->n_cu, s));
@@ -574,6 +577,13 @@ int ppqc_sync(ppqc_ctx* c) {
     return resolve_timings(c);
 }
 
+int ppqc_input_errors(ppqc_ctx* c, uint64_t* out4) {
+    if (!c || !out4) return fail(PPQC_E_INVALID, "null argument");
+    CHK(ppqc_sync(c));
+    HIPCHK(hipMemcpy(out4, c->res_buf + c->res_words, 32, hipMemcpyDeviceToHost));
+    return PPQC_OK;
+}
+
 int ppqc_n_reads(ppqc_ctx* c, uint64_t* n) {
     if (!c || !n) return fail(PPQC_E_INVALID, "null argument");
     *n = c->n_reads;
@@ -619,6 +629,21 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     HIPCHK(hipMemcpyAsync(c->maxlen_host, c->max_buf, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(c->ev_max, s));
     c->state = 1;
+    return PPQC_OK;
+}
+
+int ppqc_time_range(ppqc_ctx* c, int64_t* out2) {
+    if (!c || !out2) return fail(PPQC_E_INVALID, "null argument");
+    if (c->state < 1) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes first");
+    CHK(ppqc_sync(c));
+    HIPCHK(hipMemcpy(out2, c->tminmax, 16, hipMemcpyDeviceToHost));
+    return PPQC_OK;
+}
+
+int ppqc_set_ref_time(ppqc_ctx* c, int64_t ref_time) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    c->cfg.ref_time_s = ref_time;
+    c->tp.ref_time_s = ref_time;
     return PPQC_OK;
 }
 

@@ -37,6 +37,28 @@ __device__ __forceinline__ uint32_t vec_nl_bits(const uint4& v, int valid) {
     return bits;
 }
 
+// high bit of each byte set where a QUALITY byte is invalid: outside '!'..'~' and not ASCII white space (line ends and
+// trailing blanks are stripped, not judged)
+__device__ __forceinline__ uint32_t badq_mask(uint32_t x) {
+    const uint32_t H = 0x80808080u, hi = x & H, lo7 = x & 0x7F7F7F7Fu;
+    const uint32_t ge9 = (lo7 + 0x77777777u) & H, ge14 = (lo7 + 0x72727272u) & H, ge32 = (lo7 + 0x60606060u) & H;
+    const uint32_t ge33 = (lo7 + 0x5F5F5F5Fu) & H, ge127 = (lo7 + 0x01010101u) & H;
+    const uint32_t invalid = hi | (~ge33 & H) | ge127;
+    const uint32_t ws = ((ge9 & ~ge14) | (ge32 & ~ge33)) & ~hi;
+    return invalid & ~ws;
+}
+__device__ __forceinline__ uint32_t vec_badq_bits(const uint4& v, int valid) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t m = badq_mask(w[k]);
+        bits |= (((m >> 7) & 1u) | ((m >> 14) & 2u) | ((m >> 21) & 4u) | ((m >> 28) & 8u)) << (4 * k);
+    }
+    if (valid < 16) bits &= valid <= 0 ? 0u : ((1u << valid) - 1u);
+    return bits;
+}
+
 __device__ __forceinline__ uint4 load_vec_clamped(const uint8_t* __restrict__ text, uint64_t pos, uint64_t n) {
     // 16-byte aligned load; a vector that starts beyond the data is replaced by the last in-bounds one (masked later)
     const uint64_t last = (n - 1) & ~15ull;
@@ -144,19 +166,22 @@ hipError_t launch_nl_count_scan(const uint8_t* text, uint64_t n, const FastqScra
 // one wave per chunk again: the k-th newline of the text (0-based) at byte p sets line_off[k + 1] = p + 1
 __global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict__ text, uint64_t n,
                                                       const uint64_t* __restrict__ prefix, uint64_t n_chunks,
-                                                      uint64_t* __restrict__ line_off, uint64_t n_lines) {
+                                                      uint64_t* __restrict__ line_off, uint64_t n_lines,
+                                                      uint64_t* __restrict__ errors) {
     const int lane = threadIdx.x & 63;
     const uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0) { line_off[0] = 0; line_off[n_lines] = n; }
     if (chunk >= n_chunks) return;
     uint64_t base = uniform_u64(prefix[chunk]);
+    uint32_t nbad = 0;
     for (int it = 0; it < (int)(kNlChunk / kSpan); ++it) {
         const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
-        uint32_t bits = 0;
+        uint32_t bits = 0, bad = 0;
         if (pos < n) {
             const uint4 v = load_vec_clamped(text, pos, n);
             const uint64_t rem = n - pos;
             bits = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
+            bad = vec_badq_bits(v, rem < 16 ? (int)rem : 16);
         }
         const uint32_t cnt = __popc(bits);
         uint32_t inc = cnt;   // inclusive wave prefix of the lane counts
@@ -165,7 +190,16 @@ __global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict_
             const uint32_t u = __shfl_up(inc, o);
             if (lane >= o) inc += u;
         }
-        uint64_t k = base + (inc - cnt);
+        uint64_t k = base + (inc - cnt);   // number of the line the vector starts in
+        // quality lines are the lines 3 (mod 4): count their invalid bytes (what SeqIO rejects, lib/seq_routines.py:50)
+        if (bad) {
+            if (!bits) nbad += (k & 3) == 3 ? __popc(bad) : 0;
+            else
+                for (uint32_t m = bad; m; m &= m - 1) {
+                    const int b = __ffs((int)m) - 1;
+                    nbad += ((k + __popc(bits & ((1u << b) - 1u))) & 3) == 3;
+                }
+        }
         while (bits) {
             const int b = __ffs((int)bits) - 1;
             bits &= bits - 1;
@@ -174,13 +208,16 @@ __global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict_
         }
         base += (uint32_t)__shfl((int)inc, 63);
     }
+    nbad = (uint32_t)wave_sum_u64(nbad);
+    if (lane == 0 && nbad) atomicAdd((unsigned long long*)&errors[3], (unsigned long long)nbad);
 }
 
-hipError_t launch_nl_fill(const uint8_t* text, uint64_t n, uint64_t n_lines, const FastqScratch& fs, hipStream_t s) {
+hipError_t launch_nl_fill(const uint8_t* text, uint64_t n, uint64_t n_lines, const FastqScratch& fs, uint64_t* errors,
+                          hipStream_t s) {
     const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
     const uint64_t blocks = n_chunks ? (n_chunks + 3) / 4 : 1;
     hipLaunchKernelGGL(nl_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, text, n, fs.prefix, n_chunks, fs.line_off,
-                       n_lines);
+                       n_lines, errors);
     return hipGetLastError();
 }
 

@@ -134,7 +134,9 @@ uint64_t nl_scan_block_words(uint64_t n_chunks);
 // counts newlines per chunk and scans them; the total lands in fs.prefix[n_chunks]
 hipError_t launch_nl_count_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, hipStream_t s);
 // line_off[0] = 0, line_off[k + 1] = position after the k-th newline, line_off[n_lines] = n
-hipError_t launch_nl_fill(const uint8_t* text, uint64_t n, uint64_t n_lines, const FastqScratch& fs, hipStream_t s);
+// also counts, in errors[3], the bytes of quality lines outside '!'..'~' (white space excepted)
+hipError_t launch_nl_fill(const uint8_t* text, uint64_t n, uint64_t n_lines, const FastqScratch& fs, uint64_t* errors,
+                          hipStream_t s);
 // one thread per record: validates the four lines, strips line ends, merges the line sums into the per-read arrays,
 // parses ch= and start_time= out of the header.  errors[1] counts malformed records.
 hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,

@@ -108,6 +108,14 @@ class QCContext:
         L.check(self._lib.ppqc_submit_fastq_device(self._ctx, text_ptr, int(n_bytes), int(mux), C.byref(n)))
         return n.value
 
+    def input_errors(self):
+        """dict(bad_csr_rows, bad_fastq_records, first_bad_record, bad_quality_bytes) found on the device so far."""
+        out = np.zeros(4, np.uint64)
+        L.check(self._lib.ppqc_input_errors(self._ctx, _ptr(out)))
+        first = int(out[2])
+        return dict(bad_csr_rows=int(out[0]), bad_fastq_records=int(out[1]),
+                    first_bad_record=None if first == (1 << 64) - 1 else first, bad_quality_bytes=int(out[3]))
+
     def submit_records(self, length, mean_q, channel, mux, start_time_s, gc_count=None):
         """Reads whose statistics come from a table (albacore sequencing_summary.txt, lib/seq_routines.py:831-863)."""
         length = np.ascontiguousarray(length, dtype=np.uint32)
@@ -186,6 +194,15 @@ class QCContext:
     # phased finalize for multi-GPU merges
     def finalize_extremes(self):
         L.check(self._lib.ppqc_finalize_extremes(self._ctx))
+
+    def time_range(self):
+        out = np.zeros(2, np.int64)
+        L.check(self._lib.ppqc_time_range(self._ctx, _ptr(out)))
+        return int(out[0]), int(out[1])
+
+    def set_ref_time(self, ref_time):
+        L.check(self._lib.ppqc_set_ref_time(self._ctx, int(ref_time)))
+        self.cfg.ref_time_s = int(ref_time)
 
     def finalize_tables(self):
         L.check(self._lib.ppqc_finalize_tables(self._ctx))

@@ -511,36 +511,40 @@ def summary_channel_dict(rows, dev=None):
     return channel_dict_from_tables(tables, summary=True)
 
 
-def _stream_fastq_files(ctx, files, meta):
-    """Pack every file and push it through the two staging slots (pinned-equivalent double buffer of ppqc_submit);
-    ``meta(packed, path)`` supplies (channel, mux, start_time, fail_flag)."""
-    k = 0
-    for path in files:
-        p = fastq_io.pack_fastq(fastq_io.read_text(path))
-        if p["n_bad_qual"]:
-            raise ValueError("%s: %d quality characters outside '!'..'~' (SeqIO raises ValueError)" % (path, p["n_bad_qual"]))
-        if p["n_reads"] == 0:
-            continue
-        ch, mux, t, ff = meta(p, path)
-        ctx.submit(p["bases"], p["quals"], p["offsets"], ch, mux, t, ff, slot=k % 2)
-        k += 1
-        yield path, p
-    ctx.sync()
+def _submit_fastq_files(ctx, files, host_meta):
+    """Every file through the GPU tokenizer (ppqc_submit_fastq: the text goes to the card as it is, alternating between
+    the two staging slots).  A text the strict tokenizer refuses (blank lines between records, which SeqIO tolerates)
+    goes through the host packer instead, with ``host_meta(packed, path)`` supplying (channel, mux, time)."""
+    from ._lib import PPQCError
+    for k, path in enumerate(files):
+        text = fastq_io.read_text(path)
+        try:
+            ctx.submit_fastq(text, slot=k % 2, mux=1)
+        except PPQCError as e:
+            if "multiple of 4" not in str(e):
+                raise
+            log.debug("%s: %s; using the host packer" % (path, e))
+            p = fastq_io.pack_fastq(text)
+            if p["n_bad_qual"]:
+                raise ValueError("%s: %d quality characters outside '!'..'~' (SeqIO raises ValueError)" % (path, p["n_bad_qual"]))
+            if p["n_reads"]:
+                ch, mux, t = host_meta(p, path)
+                ctx.submit(p["bases"], p["quals"], p["offsets"], ch, mux, t, None, slot=k % 2)
+    e = ctx.input_errors()
+    if e["bad_quality_bytes"]:
+        raise ValueError("%d quality characters outside '!'..'~' (SeqIO raises ValueError)" % e["bad_quality_bytes"])
 
 
 def fastq_gc(files, dev=None):
     """``fastq_reader`` over a list of FASTQ files (:40-53): per-record (gc_count, length) from the GPU."""
     with qc.QCContext(device=device if dev is None else dev, n_channels=n_channels, n_mux=1, n_time_bins=n_hours) as ctx:
-        def meta(p, path):
-            # the reference int()s header field 3 minus its 'ch=' prefix (:51) and dies on anything else
-            if np.any(p["channel"] == 0):
-                raise ValueError("%s: record without a ch= header field" % path)
-            R = p["n_reads"]
-            return p["channel"], np.ones(R, np.uint8), np.zeros(R, np.int64), None
-        for _ in _stream_fastq_files(ctx, files, meta):
-            pass
+        _submit_fastq_files(ctx, files, lambda p, path: (p["channel"], np.ones(p["n_reads"], np.uint8),
+                                                         np.zeros(p["n_reads"], np.int64)))
         s = ctx.read_stats()
         extra = ctx.finalize() if ctx.n_reads else None
+    # the reference int()s header field 3 minus its 'ch=' prefix (:51) and dies on anything else
+    if extra is not None and int(extra["totals"][7]):
+        raise ValueError("%d FASTQ records without a usable ch= header field" % int(extra["totals"][7]))
     return s["gc"], s["length"], extra
 
 
@@ -561,36 +565,39 @@ def summary_module(fqfolder, summary_table_file, size):
 # ---------------------------------------------------------------------------------------------------------------
 
 def fastq_module(fqfolder, Fast_flag, size):
+    """FASTQ files whose albacore headers carry ch= and start_time= (no sequencing_summary.txt, no Fast5): RefTime is
+    the earliest start time.  Without -fq the text is tokenised on the GPU; with -fq the host packer keeps the records
+    for the output file."""
     files = list(fastq_io.fastq_files_any(fqfolder))
     if not files:
         log.error("no FASTQ file under %s" % fqfolder)
         sys.exit(1)
-    packed = []
-    ref = None
-    for path in files:
-        p = fastq_io.pack_fastq(fastq_io.read_text(path))
-        if p["n_bad_qual"]:
-            raise ValueError("%s: %d quality characters outside '!'..'~'" % (path, p["n_bad_qual"]))
-        ok = p["start_time"] > -(1 << 62)
-        if not ok.all() or np.any(p["channel"] == 0):
-            raise ValueError("%s: records without ch= / start_time= header fields" % path)
-        if p["n_reads"]:
-            m = int(p["start_time"].min())
-            ref = m if ref is None else min(ref, m)
-        packed.append((path, p))
+    packed, per_read = [], None
     with qc.QCContext(device=device, n_channels=n_channels, n_mux=4, n_time_bins=n_hours, bin_seconds=3600,
-                      time_mode=1, tz_offset_s=0, ref_time_s=ref or 0, fail_q=7.0) as ctx:
-        k = 0
-        for path, p in packed:
-            if p["n_reads"] == 0:
-                continue
-            # FASTQ headers carry no mux: every read is booked on mux 1
-            ctx.submit(p["bases"], p["quals"], p["offsets"], p["channel"], np.ones(p["n_reads"], np.uint8),
-                       p["start_time"], None, slot=k % 2)
-            k += 1
-        ctx.sync()
-        per_read = ctx.read_stats() if Fast_flag else None
-        tables = ctx.finalize()
+                      time_mode=1, tz_offset_s=0, ref_time_s=0, fail_q=7.0) as ctx:
+        def meta(p, path):
+            return p["channel"], np.ones(p["n_reads"], np.uint8), p["start_time"]   # no mux in FASTQ headers: mux 1
+        if Fast_flag:
+            for k, path in enumerate(files):
+                p = fastq_io.pack_fastq(fastq_io.read_text(path))
+                if p["n_bad_qual"]:
+                    raise ValueError("%s: %d quality characters outside '!'..'~'" % (path, p["n_bad_qual"]))
+                packed.append((path, p))
+                if p["n_reads"]:
+                    ctx.submit(p["bases"], p["quals"], p["offsets"], *meta(p, path), None, slot=k % 2)
+            per_read = ctx.read_stats()
+        else:
+            _submit_fastq_files(ctx, files, meta)
+        ctx.finalize_extremes()
+        tmin, _tmax = ctx.time_range()
+        if ctx.n_reads and tmin < -(1 << 62):
+            raise ValueError("FASTQ records without a start_time= header field")
+        ctx.set_ref_time(tmin if ctx.n_reads else 0)
+        ctx.finalize_tables()
+        ctx.finalize_n50()
+        tables = ctx.fetch_tables()
+    if int(tables["totals"][7]):
+        raise ValueError("%d FASTQ records without a usable ch= header field" % int(tables["totals"][7]))
     ChannelOut = channel_dict_from_tables(tables)
     if Fast_flag:
         from . import fastq_out

@@ -122,6 +122,20 @@ def test_fastq_only_mode_with_fastq_output(tmp_path, monkeypatch):
     want = b"".join(b"@read%d runid=r read=%d ch=%d start_time=%s\n%s\n+\n%s\n" % (
         r["i"], r["i"], r["ch"], _iso(base, r["sec"]).encode(), r["seq"], r["qual"]) for r in keep)
     assert gzip.decompress((tmp_path / "PyPore_results" / "fqo.fastq.gz").read_bytes()) == want
+    # without -fq the text is tokenised on the GPU; a file with blank lines between records (which SeqIO tolerates
+    # and the strict GPU tokenizer refuses) takes the host packer: same summary either way
+    t0 = _fastq_text(recs[:700], base)
+    t = t0.replace(b"\n@read5 ", b"\n\n@read5 ", 1)
+    assert len(t) == len(t0) + 1
+    (tmp_path / "in" / "a.fastq").write_bytes(t)
+    cd2, stats2, plates2 = seqstats.run(["-i", str(tmp_path / "in"), "-l", "fqg", "-f", "fastq", "-o", "res_gpu"])
+    _check_stats(stats2, po.FastStats_data(ref_cd))
+    assert plates2 == plates and dict(cd2) == dict(cd) and stats2["n50"] == stats["n50"]
+    assert not (tmp_path / "res_gpu" / "fqg.fastq.gz").exists()
+    # a record without ch= is an error (the reference dies in int(), lib/seq_routines.py:51)
+    (tmp_path / "in" / "c.fastq").write_bytes(b"@x start_time=2018-06-03T00:00:00Z\nACGT\n+\nIIII\n")
+    with pytest.raises(ValueError, match="ch="):
+        seqstats.run(["-i", str(tmp_path / "in"), "-l", "bad", "-f", "fastq"])
 
 
 def test_fast5_modes_on_stand_in_hdf5(tmp_path, monkeypatch):

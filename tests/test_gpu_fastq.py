@@ -128,3 +128,27 @@ def test_malformed_text_fails_loudly(qc_mod, bad, where):
                 ctx.read_stats()
         ctx.reset()
         assert ctx.submit_fastq(good) == 10 and int(ctx.finalize()["totals"][0]) == 10
+
+
+def test_invalid_quality_bytes_are_counted_like_the_host_packer(qc_mod):
+    from pypore_amd import fastq_io
+    rng = np.random.default_rng(8)
+    recs = []
+    for i in range(300):
+        L = int(rng.integers(1, 4000))
+        q = rng.integers(33, 127, L, dtype=np.uint8)
+        k = rng.random(L) < 0.01
+        q[k] = rng.choice(np.array([0, 1, 8, 14, 31, 127, 128, 200, 255], np.uint8), int(k.sum()))
+        # bases full of bytes that are invalid as qualities must not count; neither must CR LF line ends
+        s = rng.choice(np.array([65, 67, 71, 84, 1, 200, 127], np.uint8), L)
+        recs.append(b"@r%d ch=3\r\n" % i + bytes(s) + b"\r\n+\r\n" + bytes(q) + b"\r\n")
+    text = b"".join(recs)
+    want = fastq_io.pack_fastq(text)["n_bad_qual"]
+    assert want > 100
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        ctx.submit_fastq(text)
+        e = ctx.input_errors()
+        assert e == dict(bad_csr_rows=0, bad_fastq_records=0, first_bad_record=None, bad_quality_bytes=want)
+        ctx.finalize()                 # reported, not fatal (the bytes are clamped as in ppqc_submit)
+        ctx.reset()
+        assert ctx.input_errors()["bad_quality_bytes"] == 0
