@@ -46,6 +46,9 @@ def parse():
                     help="BASELINE config 5 instead of the headline metric: the same reads streamed from pinned host "
                          "memory as 4000-read batches through the double-buffered ppqc_submit (end to end incl. H2D)")
     ap.add_argument("--batch-reads", type=int, default=4000)
+    ap.add_argument("--fastq", action="store_true",
+                    help="FASTQ TEXT as input instead of CSR (not the headline metric): GPU tokenizer on text resident in "
+                         "HBM, the same streamed from pinned host memory file by file, and the host packer for comparison")
     ap.add_argument("--dist-path", action="store_true",
                     help="with one GPU: run the step through the multi-GPU merge path (1-rank RCCL group) to time it")
     return ap.parse_args()
@@ -102,6 +105,8 @@ def main():
     ctx.sync()
     torch.cuda.synchronize()
 
+    if a.fastq:
+        return fastq_mode(a, ctx, torch, off, ch, t, d_bases, d_quals)
     if a.stream:
         return stream_mode(a, ctx, torch, off, ch, mux, t, d_bases, d_quals, n_bytes, R)
 
@@ -215,6 +220,81 @@ def stream_mode(a, ctx, torch, off, ch, mux, t, d_bases, d_quals, n_bytes, R):
                       "bases": n_bytes}, "data": "synthetic", "dtype": "u8"}
     print(json.dumps(out), flush=True)
     pb.close(); pq.close()
+    ctx.close()
+
+
+def fastq_mode(a, ctx, torch, off, ch, t, d_bases, d_quals):
+    """FASTQ text in, tables out.  The first `--reads` (capped at 200 000) synthetic reads are written as albacore-style
+    4-line records, `batch_reads` per file."""
+    from pypore_amd import qc, fastq_io
+    R = min(len(off) - 1, 200_000)
+    nb = int(off[R])
+    hb = d_bases[:nb].cpu().numpy().tobytes()
+    hq = d_quals[:nb].cpu().numpy().tobytes()
+    files, cur = [], []
+    for i in range(R):
+        s0, s1 = int(off[i]), int(off[i + 1])
+        cur.append(b"@read%08d runid=synthetic read=%d ch=%d start_time=%s\n%s\n+\n%s\n" % (
+            i, i, int(ch[i]), time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(int(t[i]))).encode(), hb[s0:s1], hq[s0:s1]))
+        if len(cur) == a.batch_reads or i == R - 1:
+            files.append(b"".join(cur))
+            cur = []
+    del hb, hq
+    total = sum(len(f) for f in files)
+    pin = qc.PinnedBuffer(total)
+    ext, pos = [], 0
+    for f in files:
+        pin.array[pos:pos + len(f)] = np.frombuffer(f, np.uint8)
+        ext.append((pos, pos + len(f)))
+        pos += len(f)
+    d_text = torch.empty(total + 64, dtype=torch.uint8, device=d_bases.device)
+    d_text[:total].copy_(torch.from_numpy(pin.array))
+    torch.cuda.synchronize()
+    res = {}
+
+    def timed(name, fn):
+        for _ in range(a.warmup):
+            tab = fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            tab = fn()
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / a.steps
+        assert int(tab["totals"][0]) == R and int(tab["totals"][1]) == nb and int(tab["totals"][7]) == 0
+        res[name] = {"ms": round(dt * 1e3, 3), "Gbases_per_s": round(nb / dt / 1e9, 2), "text_GBps": round(total / dt / 1e9, 2)}
+        return tab
+
+    def resident():      # whole text already in HBM, one call
+        ctx.reset()
+        ctx.submit_fastq_device(d_text.data_ptr(), total)
+        return ctx.finalize()
+
+    def streamed():      # pinned host text, file by file through the two staging slots
+        ctx.reset()
+        for k, (s0, s1) in enumerate(ext):
+            ctx.submit_fastq(pin.array[s0:s1], slot=k % 2)
+        return ctx.finalize()
+
+    def host_packer():   # ppqc_fastq_scan/pack on one host thread, then the CSR path
+        ctx.reset()
+        for k, (s0, s1) in enumerate(ext):
+            p = fastq_io.pack_fastq(pin.array[s0:s1])
+            ctx.submit(p["bases"], p["quals"], p["offsets"], p["channel"], np.ones(p["n_reads"], np.uint8),
+                       p["start_time"], slot=k % 2)
+        return ctx.finalize()
+
+    ta = timed("gpu_tokenizer_text_resident_in_hbm", resident)
+    tb = timed("gpu_tokenizer_streamed_from_pinned_host", streamed)
+    tc = timed("host_packer_then_csr", host_packer)
+    same = all(np.array_equal(ta[k], tb[k]) and np.array_equal(ta[k], tc[k]) for k in
+               ("totals", "gc_hist", "q_hist", "chan_reads", "chan_bases", "chan_fail", "cmh_bases", "hour_reads"))
+    print(json.dumps({"metric": "Gbases/s per-read QC stats from FASTQ text", "unit": "Gbases/s", "n_gpus": 1,
+                      "steps": a.steps, "warmup": a.warmup, "data": "synthetic",
+                      "config": {"workload": "%d reads, %.2f Gbases, %.2f GB of FASTQ text in %d files of %d records"
+                                             % (R, nb / 1e9, total / 1e9, len(files), a.batch_reads)},
+                      "results": res, "all_three_paths_identical_tables": bool(same)}), flush=True)
+    pin.close()
     ctx.close()
 
 
