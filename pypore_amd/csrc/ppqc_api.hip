@@ -485,7 +485,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     HIPCHK(launch_nl_fill(text, n, n_lines, c->fq, c->res_buf + c->res_words, s));
     // line mode: both classifiers run over the same text, every line is a segment
     BatchView v{text, text, c->fq.line_off, n_lines, n, nullptr, shift, nullptr, nullptr, nullptr};
-    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->n_cu, s));
+    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->n_cu, s, true));
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
                                  c->lut_dev, c->tp.thr_fail, c->tp.fail_q, mux, c->res_buf + c->res_words, s));
     c->n_reads += R;

@@ -59,6 +59,12 @@ __device__ __forceinline__ uint32_t vec_badq_bits(const uint4& v, int valid) {
     return bits;
 }
 
+// nonzero iff some byte of the word lies outside '!'..'~' (newlines, other white space and invalid quality bytes)
+__device__ __forceinline__ uint32_t odd_byte_mask(uint32_t x) {
+    const uint32_t H = 0x80808080u, lo7 = x & 0x7F7F7F7Fu;
+    return ((x | (lo7 + 0x01010101u)) & H) | (~(lo7 + 0x5F5F5F5Fu) & H);
+}
+
 __device__ __forceinline__ uint4 load_vec_clamped(const uint8_t* __restrict__ text, uint64_t pos, uint64_t n) {
     // 16-byte aligned load; a vector that starts beyond the data is replaced by the last in-bounds one (masked later)
     const uint64_t last = (n - 1) & ~15ull;
@@ -174,21 +180,32 @@ __global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict_
     if (chunk >= n_chunks) return;
     uint64_t base = uniform_u64(prefix[chunk]);
     uint32_t nbad = 0;
-    for (int it = 0; it < (int)(kNlChunk / kSpan); ++it) {
+    constexpr int kIt = (int)(kNlChunk / kSpan);
+    uint4 vv[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {   // all loads of the chunk in flight before the first use
+        const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
+        vv[it] = load_vec_clamped(text, pos < n ? pos : 0, n);
+    }
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
         const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
         uint32_t bits = 0, bad = 0;
-        if (pos < n) {
-            const uint4 v = load_vec_clamped(text, pos, n);
+        // nearly every vector holds only '!'..'~' bytes: one cheap test, the exact masks only where it fires
+        const uint4& v = vv[it];
+        if (pos < n && (odd_byte_mask(v.x) | odd_byte_mask(v.y) | odd_byte_mask(v.z) | odd_byte_mask(v.w))) {
             const uint64_t rem = n - pos;
             bits = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
             bad = vec_badq_bits(v, rem < 16 ? (int)rem : 16);
         }
         const uint32_t cnt = __popc(bits);
         uint32_t inc = cnt;   // inclusive wave prefix of the lane counts
+        if (__ballot(bits != 0) != 0) {   // most 1 KiB spans lie inside one line: no newline, nothing to scan
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t u = __shfl_up(inc, o);
-            if (lane >= o) inc += u;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(inc, o);
+                if (lane >= o) inc += u;
+            }
         }
         uint64_t k = base + (inc - cnt);   // number of the line the vector starts in
         // quality lines are the lines 3 (mod 4): count their invalid bytes (what SeqIO rejects, lib/seq_routines.py:50)

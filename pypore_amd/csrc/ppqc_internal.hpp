@@ -75,7 +75,7 @@ struct TableParams {
 
 // ---- launchers (each enqueues on `s`, returns the hipError of the launch) -----------------------------------------
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
-                              Partial* head, Partial* tail, int n_cu, hipStream_t s);
+                              Partial* head, Partial* tail, int n_cu, hipStream_t s, bool line_mode = false);
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint64_t thr_fail, double fail_q, uint64_t* csr_errors,
                                  hipStream_t s);

@@ -62,6 +62,26 @@ __device__ __forceinline__ Acc vec_sums(const uint4& vb, const uint4& vq, const 
     return a;
 }
 
+// Line mode (FASTQ text, bases == quals == text): a span inside one line needs only that line's classifier.
+__device__ __forceinline__ Acc vec_sums_bases(const uint4& vb) {
+    Acc a{0, 0, 0, 0};
+    bases_word(vb.x, a.gcs, a.n);
+    bases_word(vb.y, a.gcs, a.n);
+    bases_word(vb.z, a.gcs, a.n);
+    bases_word(vb.w, a.gcs, a.n);
+    return a;
+}
+__device__ __forceinline__ Acc vec_sums_quals(const uint4& vq, const uint64_t* lut) {
+    Acc a{0, 0, 0, 0};
+    uint64_t e0 = 0, e1 = 0;
+    quals_word(vq.x, lut, a.qb, e0);
+    quals_word(vq.y, lut, a.qb, e1);
+    quals_word(vq.z, lut, a.qb, e0);
+    quals_word(vq.w, lut, a.qb, e1);
+    a.err = e0 + e1;
+    return a;
+}
+
 // Sums over the first x (0..16) bytes of the lane's vectors.
 __device__ __noinline__ Acc vec_prefix(uint4 vb, uint4 vq, int x, const uint64_t* lut) {
     Acc a{0, 0, 0, 0};
@@ -156,11 +176,22 @@ __device__ __forceinline__ void flush_read(Acc& acc, const Walk& w, const TileCt
 
 // One 1 KiB span (both streams) of the tile: fast path if it lies inside the current read, else one prefix-masked
 // pass per read boundary inside it.
+template <bool LINE>
 __device__ __forceinline__ void process_span(const uint4& vb, const uint4& vq, uint32_t sp, Walk& w, Acc& acc,
                                              const TileCtx& c) {
     const uint32_t span_rel = sp * kSpan;
     const uint64_t span_end = c.tile_start + span_rel + kSpan;   // end of the FULL span
-    const Acc tot = vec_sums(vb, vq, c.lut);
+    Acc tot;
+    if (LINE && w.re >= span_end) {
+        // segments are text lines, line number mod 4 = header / sequence / '+' / quality (wave-uniform): only the
+        // sums fastq_finalize reads are kept exact; header and '+' lines cost no arithmetic at all
+        const uint32_t ty = (uint32_t)w.r & 3u;
+        if (ty == 1u) tot = vec_sums_bases(vb);
+        else if (ty == 3u) tot = vec_sums_quals(vq, c.lut);
+        else tot = Acc{0, 0, 0, 0};
+    } else {
+        tot = vec_sums(vb, vq, c.lut);
+    }
     if (w.re >= span_end) {
         acc_add(acc, tot);
         if (w.re == span_end) {
@@ -190,7 +221,7 @@ __device__ __forceinline__ void process_span(const uint4& vb, const uint4& vq, u
     }
 }
 
-template <int NB, bool NT>
+template <int NB, bool NT, bool LINE>
 __device__ __forceinline__ void load_batch(uint4 (&vb)[NB], uint4 (&vq)[NB], const uint8_t* __restrict__ pb,
                                            const uint8_t* __restrict__ pq, uint32_t s0, uint32_t lane_off,
                                            uint32_t last_vec) {
@@ -198,7 +229,10 @@ __device__ __forceinline__ void load_batch(uint4 (&vb)[NB], uint4 (&vq)[NB], con
     for (int i = 0; i < NB; ++i) {
         uint32_t o = (s0 + i) * kSpan + lane_off;
         o = o < last_vec ? o : last_vec;   // clamp instead of predicating: out-of-range lanes are masked by the walk
-        if (NT) {   // read-once streams: nontemporal loads (measured +16 % on MI355X)
+        if (LINE) {   // one stream: the text is both
+            const u32x4 tb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pb + o));
+            vb[i] = make_uint4(tb[0], tb[1], tb[2], tb[3]);
+        } else if (NT) {   // read-once streams: nontemporal loads (measured +16 % on MI355X)
             const u32x4 tb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pb + o));
             const u32x4 tq = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pq + o));
             vb[i] = make_uint4(tb[0], tb[1], tb[2], tb[3]);
@@ -210,21 +244,21 @@ __device__ __forceinline__ void load_batch(uint4 (&vb)[NB], uint4 (&vq)[NB], con
     }
 }
 
-template <int NB>
+template <int NB, bool LINE>
 __device__ __forceinline__ void process_batch(const uint4 (&vb)[NB], const uint4 (&vq)[NB], uint32_t s0,
                                               uint32_t n_spans, Walk& w, Acc& acc, const TileCtx& c) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         if (s0 + i >= n_spans || w.done) break;
-        process_span(vb[i], vq[i], s0 + i, w, acc, c);
+        process_span<LINE>(vb[i], LINE ? vb[i] : vq[i], s0 + i, w, acc, c);
     }
 }
 
 // NB spans per batch; NT nontemporal loads; PIPE: two register sets, the next batch is in flight while one is processed.
-template <int NB, bool NT, bool PIPE>
-__global__ __launch_bounds__(256) void tile_kernel(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra,
-                                                   uint64_t read_base, Partial* __restrict__ head,
-                                                   Partial* __restrict__ tail, uint64_t n_tiles) {
+template <int NB, bool NT, bool PIPE, bool LINE>
+__device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __restrict__ lut_g, const ReadArrays& ra,
+                                          uint64_t read_base, Partial* __restrict__ head, Partial* __restrict__ tail,
+                                          uint64_t n_tiles) {
     __shared__ uint64_t lut[256];
     lut[threadIdx.x] = lut_g[threadIdx.x];
     __syncthreads();
@@ -248,7 +282,7 @@ __global__ __launch_bounds__(256) void tile_kernel(BatchView b, const uint64_t* 
         c.t = t; c.tile_start = tile_start;
 
         uint4 vb[NB], vq[NB];
-        load_batch<NB, NT>(vb, vq, pb, pq, 0, c.lane_off, last_vec);   // in flight during the read search
+        load_batch<NB, NT, LINE>(vb, vq, pb, pq, 0, c.lane_off, last_vec);   // in flight during the read search
 
         Walk w;
         w.r = find_read(c.off, c.R, tile_start, lane);
@@ -260,15 +294,15 @@ __global__ __launch_bounds__(256) void tile_kernel(BatchView b, const uint64_t* 
         if (PIPE) {
             uint4 ub[NB], uq[NB];
             for (uint32_t s0 = 0; s0 < n_spans && !w.done; s0 += 2 * NB) {
-                if (s0 + NB < n_spans) load_batch<NB, NT>(ub, uq, pb, pq, s0 + NB, c.lane_off, last_vec);
-                process_batch<NB>(vb, vq, s0, n_spans, w, acc, c);
-                if (s0 + 2 * NB < n_spans) load_batch<NB, NT>(vb, vq, pb, pq, s0 + 2 * NB, c.lane_off, last_vec);
-                if (s0 + NB < n_spans) process_batch<NB>(ub, uq, s0 + NB, n_spans, w, acc, c);
+                if (s0 + NB < n_spans) load_batch<NB, NT, LINE>(ub, uq, pb, pq, s0 + NB, c.lane_off, last_vec);
+                process_batch<NB, LINE>(vb, vq, s0, n_spans, w, acc, c);
+                if (s0 + 2 * NB < n_spans) load_batch<NB, NT, LINE>(vb, vq, pb, pq, s0 + 2 * NB, c.lane_off, last_vec);
+                if (s0 + NB < n_spans) process_batch<NB, LINE>(ub, uq, s0 + NB, n_spans, w, acc, c);
             }
         } else {
             for (uint32_t s0 = 0; s0 < n_spans && !w.done; s0 += NB) {
-                if (s0) load_batch<NB, NT>(vb, vq, pb, pq, s0, c.lane_off, last_vec);
-                process_batch<NB>(vb, vq, s0, n_spans, w, acc, c);
+                if (s0) load_batch<NB, NT, LINE>(vb, vq, pb, pq, s0, c.lane_off, last_vec);
+                process_batch<NB, LINE>(vb, vq, s0, n_spans, w, acc, c);
             }
         }
         // a read that continues into the next tile leaves a partial: tail if it started here, else head
@@ -277,6 +311,22 @@ __global__ __launch_bounds__(256) void tile_kernel(BatchView b, const uint64_t* 
             flush(acc, lane, &p->cnt, &p->hi, &p->lo);
         }
     }
+}
+
+template <int NB, bool NT, bool PIPE>
+__global__ __launch_bounds__(256) void tile_kernel(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra,
+                                                   uint64_t read_base, Partial* __restrict__ head,
+                                                   Partial* __restrict__ tail, uint64_t n_tiles) {
+    tile_body<NB, NT, PIPE, false>(b, lut_g, ra, read_base, head, tail, n_tiles);
+}
+
+// Line mode (FASTQ text): one stream.  8 spans per batch at 5 waves per SIMD (95 VGPRs); 16 spans spill (measured
+// 1.0 TB/s of text against 1.27 TB/s for the whole tokenizer path).
+template <int NB>
+__global__ __launch_bounds__(256)
+void tile_kernel_line(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra, uint64_t read_base,
+                      Partial* __restrict__ head, Partial* __restrict__ tail, uint64_t n_tiles) {
+    tile_body<NB, true, false, true>(b, lut_g, ra, read_base, head, tail, n_tiles);
 }
 
 // One thread per read: merge the partials of reads that span tiles, define empty reads, then decode the raw sums.
@@ -329,7 +379,7 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
     ra.time[g] = b.time[i];
 }
 
-template <int NB, bool NT, bool PIPE>
+template <int NB, bool NT, bool PIPE, bool LINE = false>
 static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
                                       Partial* head, Partial* tail, int n_cu, int blocks_per_cu, hipStream_t s) {
     const uint64_t n_tiles = (b.n_bytes + (1ull << b.tile_shift) - 1) >> b.tile_shift;
@@ -342,15 +392,20 @@ static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_de
         if (blocks > cap) blocks = cap;
     }
     if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
-    hipLaunchKernelGGL((tile_kernel<NB, NT, PIPE>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head,
-                       tail, n_tiles);
+    if (LINE)
+        hipLaunchKernelGGL((tile_kernel_line<NB>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base,
+                           head, tail, n_tiles);
+    else
+        hipLaunchKernelGGL((tile_kernel<NB, NT, PIPE>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra,
+                           read_base, head, tail, n_tiles);
     return hipGetLastError();
 }
 
 // PPQC_TILE_VARIANT / PPQC_TILE_BLOCKS_PER_CU are tuning knobs for A/B measurements; the default is the shipped one.
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
-                              Partial* head, Partial* tail, int n_cu, hipStream_t s) {
+                              Partial* head, Partial* tail, int n_cu, hipStream_t s, bool line_mode) {
     if (b.n_bytes == 0 || b.n_reads == 0) return hipSuccess;
+    if (line_mode) return launch_tile_variant<8, true, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, 0, s);
     const char* v = getenv("PPQC_TILE_VARIANT");
     const char* bp = getenv("PPQC_TILE_BLOCKS_PER_CU");
     const int bpc = bp ? atoi(bp) : 0;
