@@ -82,8 +82,9 @@ __device__ __forceinline__ Acc vec_sums_quals(const uint4& vq, const uint64_t* l
     return a;
 }
 
-// Sums over the first x (0..16) bytes of the lane's vectors.
-__device__ __noinline__ Acc vec_prefix(uint4 vb, uint4 vq, int x, const uint64_t* lut) {
+// Sums over the first x (0..16) bytes of the lane's vectors, lean version for the long-read kernel (which must stay
+// within 128 VGPRs): per-word masks, LUT entries added under a predicate.
+__device__ __noinline__ Acc vec_prefix_lean(uint4 vb, uint4 vq, int x, const uint64_t* lut) {
     Acc a{0, 0, 0, 0};
     const uint32_t wb[4] = {vb.x, vb.y, vb.z, vb.w};
     const uint32_t wq[4] = {vq.x, vq.y, vq.z, vq.w};
@@ -104,6 +105,23 @@ __device__ __noinline__ Acc vec_prefix(uint4 vb, uint4 vq, int x, const uint64_t
     return a;
 }
 
+// The same for the short-read / line-mode kernels: the bytes from x on are zeroed (a zero byte matches no
+// base class and adds nothing to the byte sum) and their LUT entries, lut[0] = 2^52 each, are taken off again.
+__device__ __noinline__ Acc vec_prefix(uint4 vb, uint4 vq, int x, const uint64_t* lut) {
+    uint32_t m[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        int k = x - 4 * w;
+        k = k < 0 ? 0 : (k > 4 ? 4 : k);
+        m[w] = (uint32_t)((1ull << (8 * k)) - 1ull);
+    }
+    const uint4 mb = make_uint4(vb.x & m[0], vb.y & m[1], vb.z & m[2], vb.w & m[3]);
+    const uint4 mq = make_uint4(vq.x & m[0], vq.y & m[1], vq.z & m[2], vq.w & m[3]);
+    Acc a = vec_sums(mb, mq, lut);
+    a.err -= (uint64_t)(kVec - x) << PPQC_ERR_SHIFT;
+    return a;
+}
+
 __device__ __forceinline__ void acc_add(Acc& a, const Acc& b) {
     a.gcs += b.gcs; a.n += b.n; a.qb += b.qb; a.err += b.err;
 }
@@ -117,19 +135,10 @@ struct Walk {
     uint64_t rs;   // its first byte
     uint64_t re;   // one past its last byte
     bool done;     // no read left
+    // window of upcoming read ends, one per lane: lane i holds offsets[win_r0 + 1 + i] (the end of read win_r0 + i)
+    uint64_t win, win_r0;
+    bool win_ok;
 };
-
-__device__ __forceinline__ void walk_advance(Walk& w, const uint64_t* __restrict__ off, uint64_t R) {
-    w.rs = w.re;
-    uint64_t r = w.r + 1;
-    while (r < R) {
-        const uint64_t e = uniform_u64(off[r + 1]);
-        if (e != w.rs) { w.re = e; break; }   // skip empty reads
-        ++r;
-    }
-    w.r = r;
-    w.done = r >= R;
-}
 
 // Largest r in [0, R) with off[r] <= pos (pos < off[R]); 64-ary search, one probe per lane per round.
 __device__ __forceinline__ uint64_t find_read(const uint64_t* __restrict__ off, uint64_t R, uint64_t pos, int lane) {
@@ -163,7 +172,40 @@ struct TileCtx {
     const uint64_t* lut;
     int lane;
     uint32_t lane_off;
+    uint32_t* xs;   // 64 words of LDS per wave (boundary_rounds)
 };
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// offsets[r + 1] (the end of read r < R) out of the register window; one coalesced load refills it every 64 reads, so
+// a boundary does not wait for a dependent global load
+__device__ __forceinline__ uint64_t read_end(Walk& w, const TileCtx& c, uint64_t r) {
+    if (!w.win_ok || r < w.win_r0 || r - w.win_r0 >= 64) {
+        uint64_t idx = r + 1 + (uint64_t)c.lane;
+        idx = idx < c.R ? idx : c.R;
+        w.win = c.off[idx];
+        w.win_r0 = r;
+        w.win_ok = true;
+    }
+    return readlane_u64(w.win, (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r - w.win_r0)));
+}
+
+template <bool WIN>
+__device__ __forceinline__ void walk_advance(Walk& w, const TileCtx& c) {
+    w.rs = w.re;
+    uint64_t r = w.r + 1;
+    while (r < c.R) {
+        const uint64_t e = WIN ? read_end(w, c, r) : uniform_u64(c.off[r + 1]);
+        if (e != w.rs) { w.re = e; break; }   // skip empty reads
+        ++r;
+    }
+    w.r = r;
+    w.done = r >= c.R;
+}
 
 __device__ __forceinline__ void flush_read(Acc& acc, const Walk& w, const TileCtx& c) {
     // a read that ends here is complete if it also started in this tile, else this is the head partial of the tile
@@ -174,9 +216,89 @@ __device__ __forceinline__ void flush_read(Acc& acc, const Walk& w, const TileCt
           whole ? &c.ra.rec_lo[ri] : &p->lo);
 }
 
-// One 1 KiB span (both streams) of the tile: fast path if it lies inside the current read, else one prefix-masked
-// pass per read boundary inside it.
-template <bool LINE>
+// A span that contains read boundaries, all of them at once.  Lane i of the offsets window owns the read that ends at
+// win_i; lane v of the data owns 16 bytes.  With E = exclusive wave scan of the per-lane sums and pre_v = sums over the
+// first x bytes of lane v (x = where a boundary cuts lane v's vector; ONE masked pass serves every boundary of the
+// span), the sums from the span start to boundary i are P_i = E[vl_i] + pre[vl_i], and the read owns P_i - P_(i-1).
+// The first read also owns what earlier spans left in acc (one wave reduction per span, not per read); the others
+// started inside this span and are stored by their own lanes.  Returns false when two different cuts fall into one
+// 16-byte vector (reads shorter than 16 bytes): the sequential loop finishes the span from the state left here.
+__device__ __forceinline__ bool boundary_rounds(const uint4& vb, const uint4& vq, const Acc& tot, uint64_t span_start,
+                                                uint64_t span_end, Walk& w, Acc& acc, Acc& prev, const TileCtx& c) {
+    const int lane = c.lane;
+    const uint64_t tc = pack_cnt(tot.gcs, tot.n, tot.qb), te = tot.err;   // span level: err <= 1 KiB * 2^52 fits u64
+    uint64_t ic = tc, ie = te;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t uc = __shfl_up(ic, o), ue = __shfl_up(ie, o);
+        if (lane >= o) { ic += uc; ie += ue; }
+    }
+    const uint64_t Ec = ic - tc, Ee = ie - te;
+    uint64_t baseC = 0, baseE = 0;   // P of the last boundary of the previous round
+    bool first = true, ok = true;
+    for (;;) {
+        int pos = (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w.r - w.win_r0));
+        if (!w.win_ok || w.r < w.win_r0 || w.r - w.win_r0 >= 64) {
+            uint64_t idx = w.r + 1 + (uint64_t)lane;
+            idx = idx < c.R ? idx : c.R;
+            w.win = c.off[idx];
+            w.win_r0 = w.r;
+            w.win_ok = true;
+            pos = 0;
+        }
+        const bool isb = lane >= pos && w.win_r0 + (uint64_t)lane < c.R && w.win < span_end;
+        const uint64_t nbm = __ballot(isb);
+        if (!nbm) break;
+        const uint32_t rel = isb ? (uint32_t)(w.win - span_start) : 0u;
+        const int vl = (int)(rel >> 4), x = (int)(rel & 15u);
+        const int vlp = __shfl_up(vl, 1), xp = __shfl_up(x, 1);
+        if (__ballot(isb && lane > pos && vlp == vl && xp != x)) { ok = false; break; }
+        // tell every data lane where its vector is cut (0 = not cut)
+        c.xs[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (isb) c.xs[vl] = (uint32_t)x;
+        __builtin_amdgcn_wave_barrier();
+        const int myx = (int)c.xs[lane];
+        __builtin_amdgcn_wave_barrier();
+        Acc pre{0, 0, 0, 0};
+        if (__ballot(myx != 0)) pre = vec_prefix(vb, vq, myx, c.lut);
+        const uint64_t Qc = Ec + pack_cnt(pre.gcs, pre.n, pre.qb), Qe = Ee + pre.err;
+        const uint64_t Pc = __shfl(Qc, vl), Pe = __shfl(Qe, vl);
+        uint64_t pc = __shfl_up(Pc, 1), pe = __shfl_up(Pe, 1);
+        if (lane == pos) { pc = baseC; pe = baseE; }
+        const uint64_t sc = Pc - pc, se = Pe - pe;   // cumulative, so no field of the packed counters borrows
+        if (first) {
+            const uint64_t fc = readlane_u64(sc, pos), fe = readlane_u64(se, pos);
+            if (lane == 0) { acc.gcs += cnt_gcs(fc); acc.n += cnt_n(fc); acc.qb += cnt_qb(fc); acc.err += fe; }
+            flush_read(acc, w, c);
+        }
+        if (isb && !(first && lane == pos)) {
+            const uint64_t ri = c.read_base + w.win_r0 + (uint64_t)lane;
+            c.ra.rec_cnt[ri] = sc;
+            c.ra.rec_hi[ri] = se >> 32;
+            c.ra.rec_lo[ri] = se & 0xffffffffull;
+        }
+        const int hb = 63 - __clzll((long long)nbm);
+        baseC = readlane_u64(Pc, hb);
+        baseE = readlane_u64(Pe, hb);
+        const int lvl = __builtin_amdgcn_readlane(vl, hb);
+        prev = lane < lvl ? tot : (lane == lvl ? pre : Acc{0, 0, 0, 0});
+        w.rs = readlane_u64(w.win, hb);
+        w.r = w.win_r0 + (uint64_t)hb + 1;
+        first = false;
+        if (hb != 63 || w.r >= c.R) break;   // else the window is used up and more reads may end in this span
+    }
+    w.done = w.r >= c.R;
+    if (!w.done) {
+        const uint64_t d = w.r - w.win_r0;
+        w.re = (w.win_ok && w.r >= w.win_r0 && d < 64) ? readlane_u64(w.win, (int)d) : uniform_u64(c.off[w.r + 1]);
+    }
+    return ok;
+}
+
+// One 1 KiB span (both streams) of the tile: fast path if it lies inside the current read, else the vectorised
+// boundary pass above (or, for reads shorter than a vector, one prefix-masked pass per boundary).
+template <bool LINE, bool VECB>
 __device__ __forceinline__ void process_span(const uint4& vb, const uint4& vq, uint32_t sp, Walk& w, Acc& acc,
                                              const TileCtx& c) {
     const uint32_t span_rel = sp * kSpan;
@@ -196,26 +318,27 @@ __device__ __forceinline__ void process_span(const uint4& vb, const uint4& vq, u
         acc_add(acc, tot);
         if (w.re == span_end) {
             flush_read(acc, w, c);
-            walk_advance(w, c.off, c.R);
+            walk_advance<VECB>(w, c);
         }
     } else {
         // one or more reads end strictly inside this span (or the data ends inside it)
         Acc prev{0, 0, 0, 0};
         const int vrel = (int)(span_rel + c.lane_off);
-        do {
+        const bool finished = VECB && boundary_rounds(vb, vq, tot, c.tile_start + span_rel, span_end, w, acc, prev, c);
+        if (!finished && !w.done && w.re < span_end) do {
             int x = (int)(uint32_t)(w.re - c.tile_start) - vrel;
             x = x < 0 ? 0 : (x > kVec ? kVec : x);
-            const Acc f = vec_prefix(vb, vq, x, c.lut);
+            const Acc f = VECB ? vec_prefix(vb, vq, x, c.lut) : vec_prefix_lean(vb, vq, x, c.lut);
             acc_add(acc, acc_sub(f, prev));
             prev = f;
             flush_read(acc, w, c);
-            walk_advance(w, c.off, c.R);
+            walk_advance<VECB>(w, c);
         } while (!w.done && w.re < span_end);
         if (!w.done) {
             acc = acc_sub(tot, prev);   // the read that starts in this span owns the rest of it
             if (w.re == span_end) {
                 flush_read(acc, w, c);   // starts and ends in this tile
-                walk_advance(w, c.off, c.R);
+                walk_advance<VECB>(w, c);
             }
         }
     }
@@ -244,22 +367,23 @@ __device__ __forceinline__ void load_batch(uint4 (&vb)[NB], uint4 (&vq)[NB], con
     }
 }
 
-template <int NB, bool LINE>
+template <int NB, bool LINE, bool VECB>
 __device__ __forceinline__ void process_batch(const uint4 (&vb)[NB], const uint4 (&vq)[NB], uint32_t s0,
                                               uint32_t n_spans, Walk& w, Acc& acc, const TileCtx& c) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         if (s0 + i >= n_spans || w.done) break;
-        process_span<LINE>(vb[i], LINE ? vb[i] : vq[i], s0 + i, w, acc, c);
+        process_span<LINE, VECB>(vb[i], LINE ? vb[i] : vq[i], s0 + i, w, acc, c);
     }
 }
 
 // NB spans per batch; NT nontemporal loads; PIPE: two register sets, the next batch is in flight while one is processed.
-template <int NB, bool NT, bool PIPE, bool LINE>
+template <int NB, bool NT, bool PIPE, bool LINE, bool VECB>
 __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __restrict__ lut_g, const ReadArrays& ra,
                                           uint64_t read_base, Partial* __restrict__ head, Partial* __restrict__ tail,
                                           uint64_t n_tiles) {
     __shared__ uint64_t lut[256];
+    __shared__ uint32_t xs[4][64];
     lut[threadIdx.x] = lut_g[threadIdx.x];
     __syncthreads();
 
@@ -269,7 +393,7 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
     const uint64_t kTile = 1ull << b.tile_shift;
     TileCtx c;
     c.read_base = read_base; c.R = b.n_reads; c.off = b.offsets; c.ra = ra; c.head = head; c.lut = lut;
-    c.lane = lane; c.lane_off = (uint32_t)lane * kVec;
+    c.lane = lane; c.lane_off = (uint32_t)lane * kVec; c.xs = &xs[wib][0];
 
     for (uint64_t t = (uint64_t)blockIdx.x * 4 + wib; t < n_tiles; t += n_waves) {
         const uint64_t tile_start = t << b.tile_shift;
@@ -287,22 +411,23 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
         Walk w;
         w.r = find_read(c.off, c.R, tile_start, lane);
         w.rs = uniform_u64(c.off[w.r]);
-        w.re = uniform_u64(c.off[w.r + 1]);
         w.done = false;
+        w.win = 0; w.win_r0 = 0; w.win_ok = false;
+        w.re = VECB ? read_end(w, c, w.r) : uniform_u64(c.off[w.r + 1]);
         Acc acc{0, 0, 0, 0};
 
         if (PIPE) {
             uint4 ub[NB], uq[NB];
             for (uint32_t s0 = 0; s0 < n_spans && !w.done; s0 += 2 * NB) {
                 if (s0 + NB < n_spans) load_batch<NB, NT, LINE>(ub, uq, pb, pq, s0 + NB, c.lane_off, last_vec);
-                process_batch<NB, LINE>(vb, vq, s0, n_spans, w, acc, c);
+                process_batch<NB, LINE, VECB>(vb, vq, s0, n_spans, w, acc, c);
                 if (s0 + 2 * NB < n_spans) load_batch<NB, NT, LINE>(vb, vq, pb, pq, s0 + 2 * NB, c.lane_off, last_vec);
-                if (s0 + NB < n_spans) process_batch<NB, LINE>(ub, uq, s0 + NB, n_spans, w, acc, c);
+                if (s0 + NB < n_spans) process_batch<NB, LINE, VECB>(ub, uq, s0 + NB, n_spans, w, acc, c);
             }
         } else {
             for (uint32_t s0 = 0; s0 < n_spans && !w.done; s0 += NB) {
                 if (s0) load_batch<NB, NT, LINE>(vb, vq, pb, pq, s0, c.lane_off, last_vec);
-                process_batch<NB, LINE>(vb, vq, s0, n_spans, w, acc, c);
+                process_batch<NB, LINE, VECB>(vb, vq, s0, n_spans, w, acc, c);
             }
         }
         // a read that continues into the next tile leaves a partial: tail if it started here, else head
@@ -313,11 +438,14 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
     }
 }
 
-template <int NB, bool NT, bool PIPE>
+// VECB: read boundaries of a span handled all at once (boundary_rounds) instead of one masked pass each.  It costs 16
+// VGPRs (144 instead of 128: 3 instead of 4 waves per SIMD), so it is a separate instantiation that the launcher picks
+// for batches of short reads, where boundaries dominate; long reads keep the leaner kernel.
+template <int NB, bool NT, bool PIPE, bool VECB>
 __global__ __launch_bounds__(256) void tile_kernel(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra,
                                                    uint64_t read_base, Partial* __restrict__ head,
                                                    Partial* __restrict__ tail, uint64_t n_tiles) {
-    tile_body<NB, NT, PIPE, false>(b, lut_g, ra, read_base, head, tail, n_tiles);
+    tile_body<NB, NT, PIPE, false, VECB>(b, lut_g, ra, read_base, head, tail, n_tiles);
 }
 
 // Line mode (FASTQ text): one stream.  8 spans per batch at 5 waves per SIMD (95 VGPRs); 16 spans spill (measured
@@ -326,7 +454,7 @@ template <int NB>
 __global__ __launch_bounds__(256)
 void tile_kernel_line(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra, uint64_t read_base,
                       Partial* __restrict__ head, Partial* __restrict__ tail, uint64_t n_tiles) {
-    tile_body<NB, true, false, true>(b, lut_g, ra, read_base, head, tail, n_tiles);
+    tile_body<NB, true, false, true, true>(b, lut_g, ra, read_base, head, tail, n_tiles);
 }
 
 // One thread per read: merge the partials of reads that span tiles, define empty reads, then decode the raw sums.
@@ -379,7 +507,9 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
     ra.time[g] = b.time[i];
 }
 
-template <int NB, bool NT, bool PIPE, bool LINE = false>
+constexpr uint64_t kVecbMeanLen = 1280;   // mean read length (bytes) below which the VECB kernel is launched
+
+template <int NB, bool NT, bool PIPE, bool LINE = false, bool VECB = false>
 static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
                                       Partial* head, Partial* tail, int n_cu, int blocks_per_cu, hipStream_t s) {
     const uint64_t n_tiles = (b.n_bytes + (1ull << b.tile_shift) - 1) >> b.tile_shift;
@@ -396,7 +526,7 @@ static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_de
         hipLaunchKernelGGL((tile_kernel_line<NB>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base,
                            head, tail, n_tiles);
     else
-        hipLaunchKernelGGL((tile_kernel<NB, NT, PIPE>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra,
+        hipLaunchKernelGGL((tile_kernel<NB, NT, PIPE, VECB>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra,
                            read_base, head, tail, n_tiles);
     return hipGetLastError();
 }
@@ -416,8 +546,20 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
         case 3: return launch_tile_variant<8, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
         case 4: return launch_tile_variant<4, true, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
         case 5: return launch_tile_variant<2, true, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-        case 6: return launch_tile_variant<16, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-        default: return launch_tile_variant<8, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        case 6: return launch_tile_variant<6, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        case 10: return launch_tile_variant<10, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        case 12: return launch_tile_variant<12, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        case 106: return launch_tile_variant<6, true, false, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        case 108: return launch_tile_variant<8, true, false, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        case 110: return launch_tile_variant<10, true, false, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        default: {
+            // short reads: boundaries dominate, take the kernel that handles them wave-parallel (threshold measured,
+            // see DESIGN.md); PPQC_TILE_VECB=0|1 forces one of them for A/B runs
+            const char* vb = getenv("PPQC_TILE_VECB");
+            const bool vecb = vb ? atoi(vb) != 0 : b.n_bytes / b.n_reads < kVecbMeanLen;
+            if (vecb) return launch_tile_variant<8, true, false, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+            return launch_tile_variant<8, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        }
     }
 }
 
