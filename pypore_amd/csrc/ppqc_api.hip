@@ -54,6 +54,8 @@ struct ppqc_ctx {
     ppqc_config cfg{};
     TableParams tp{};
     hipStream_t stream = nullptr, own_stream = nullptr, copy[2] = {nullptr, nullptr};
+    hipStream_t aux = nullptr;      // the sort + N50 chain runs here, beside the tables kernel on `stream`
+    hipEvent_t ev_join = nullptr;
     uint64_t* lut_dev = nullptr;
 
     ReadArrays ra{};
@@ -70,6 +72,7 @@ struct ppqc_ctx {
              *sel_state = nullptr;
     int64_t* tminmax = nullptr;
     int state = 0;   // 0 reads only, 1 extremes done, 2 tables done, 3 n50 done
+    bool sum_fetched = false;   // ppqc_finalize: the SUM tables were copied to res_host behind the tables kernel
     uint64_t n50 = 0;
 
     // sort / mode-1 scratch
@@ -254,6 +257,8 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventCreate(&c->ev_t0)); HIPCHK(hipEventCreate(&c->ev_t1));
     HIPCHK(hipEventCreate(&c->ev_s0)); HIPCHK(hipEventCreate(&c->ev_s1));
     HIPCHK(hipEventCreateWithFlags(&c->ev_max, hipEventDisableTiming));
+    HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&c->maxlen_host, 64, hipHostMallocDefault));
 
     // error-probability LUT: e[b] = round(2^52 * 10^(-q/10)), q = clamp(b - 33, 0, 93)
@@ -309,6 +314,8 @@ int ppqc_destroy(ppqc_ctx* c) {
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->maxlen_host) (void)hipHostFree(c->maxlen_host);
     if (c->ev_max) (void)hipEventDestroy(c->ev_max);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
     for (int i = 0; i < 2; ++i) {
         Slot& s = c->slot[i];
         void* sp[] = {s.bases, s.quals, s.mux, s.ff, s.offsets, s.channel, s.time};
@@ -330,9 +337,7 @@ int ppqc_reset(ppqc_ctx* c) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemsetAsync(c->res_buf + c->res_words, 0, 16, c->stream));
-    HIPCHK(hipMemsetAsync(c->res_buf + c->res_words + 2, 0xFF, 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->res_buf + c->res_words + 3, 0, 8, c->stream));
+    HIPCHK(launch_reset_errors(c->res_buf + c->res_words, c->stream));
     c->n_reads = 0;
     c->state = 0;
     c->n50 = 0;
@@ -621,13 +626,11 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    c->sum_fetched = false;
     HIPCHK(hipEventRecord(c->ev_t0, s));
     HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, s));
     HIPCHK(launch_extremes(c->ra, c->n_reads, c->tp, c->max_buf, c->min_buf, c->tminmax, s));
-    // the sort needs max_len on the host (which key bytes to pass over): fetch it now, so that the round trip hides
-    // behind the tables kernel instead of draining the stream later (a merged max_len only adds passes, never loses one)
-    HIPCHK(hipMemcpyAsync(c->maxlen_host, c->max_buf, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipEventRecord(c->ev_max, s));
+    HIPCHK(hipEventRecord(c->ev_max, s));   // fork point of the sort + N50 chain (ppqc_finalize_n50)
     c->state = 1;
     return PPQC_OK;
 }
@@ -680,40 +683,53 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
     return PPQC_OK;
 }
 
-int ppqc_finalize_n50(ppqc_ctx* c, const uint32_t* dlens, uint64_t n) {
+static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, bool early_fetch) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     if (c->state < 1) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes first");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     if (!dlens) { dlens = c->ra.lens32; n = c->n_reads; }
     if (n >= (1ull << 32)) return fail(PPQC_E_RANGE, "more than 2^32-1 lengths");
-    HIPCHK(hipEventRecord(c->ev_s0, s));
-    uint64_t maxlen;
-    if (dlens == c->ra.lens32) {   // local lengths: the copy enqueued by ppqc_finalize_extremes
-        HIPCHK(hipEventSynchronize(c->ev_max));
-        maxlen = *c->maxlen_host;
-    } else {                       // gathered lengths of other ranks: bounded by the merged max_len
-        HIPCHK(hipMemcpyAsync(c->maxlen_host, c->max_buf, 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        maxlen = *c->maxlen_host;
-    }
+    // The sort passes are gated on the device by max_buf[0] (the local or merged max_len bounds every key), so nothing
+    // here waits for the host.  Local lengths: the chain depends only on the extremes kernel and runs on the auxiliary
+    // stream beside the tables kernel (fork at ev_max, join before anything else is enqueued on the main stream).
+    // time_mode 1 sorts on the main stream with the same count buffer, so there the chain stays in line.
+    const bool local = dlens == c->ra.lens32;
+    hipStream_t ss = (local && c->cfg.time_mode == 0) ? c->aux : s;
     CHK(ensure_sort32(c, n ? n : 1));
-    if (n) HIPCHK(hipMemcpyAsync(c->sk32, dlens, n * 4, hipMemcpyDeviceToDevice, s));
-    HIPCHK(sort_u32(c->sk32, c->sk32_tmp, n, c->counts, bytes_mask_for(maxlen), s));
-    HIPCHK(launch_n50(c->sk32, n, c->n50_blocks, c->n50_out, s));
-    HIPCHK(hipEventRecord(c->ev_s1, s));
+    if (ss != s) HIPCHK(hipStreamWaitEvent(ss, c->ev_max, 0));
+    HIPCHK(hipEventRecord(c->ev_s0, ss));
+    HIPCHK(sort_u32_gated(dlens, c->sk32, c->sk32_tmp, n, c->counts, c->max_buf, ss));
+    HIPCHK(launch_n50_gated(dlens, c->sk32, c->sk32_tmp, c->max_buf, n, c->n50_blocks, c->n50_out, ss));
+    HIPCHK(hipEventRecord(c->ev_s1, ss));
+    if (ss != s) {
+        if (early_fetch && c->state == 2) {
+            // the SUM tables are final once the tables kernel is done: their copy to the host (1.6 MB at 512x4x48)
+            // goes on the main stream now, beside the sort chain, and ppqc_fetch_tables only adds the few KB behind them
+            HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, c->tp.lay.n_sum * 8, hipMemcpyDeviceToHost, s));
+            c->sum_fetched = true;
+        }
+        HIPCHK(hipEventRecord(c->ev_join, ss));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+    }
     HIPCHK(hipEventRecord(c->ev_t1, s));
     c->state = 3;
     return PPQC_OK;
 }
 
+int ppqc_finalize_n50(ppqc_ctx* c, const uint32_t* dlens, uint64_t n) { return finalize_n50_impl(c, dlens, n, false); }
+
 int ppqc_fetch_tables(ppqc_ctx* c, ppqc_tables* o) {
     if (!c || !o) return fail(PPQC_E_INVALID, "null argument");
     if (c->state < 3) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes/tables/n50 first");
-    CHK(ppqc_sync(c));
+    HIPCHK(hipSetDevice(c->device));
     const TableLayout& l = c->tp.lay;
-    HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, (c->res_words + 3) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // stream-ordered behind the last finalize kernel: one host synchronisation for the whole step
+    const uint64_t skip = c->sum_fetched ? c->tp.lay.n_sum : 0;
+    HIPCHK(hipMemcpyAsync(c->res_host + skip, c->res_buf + skip, (c->res_words + 3 - skip) * 8, hipMemcpyDeviceToHost,
+                          c->stream));
+    c->sum_fetched = false;
+    CHK(ppqc_sync(c));
     const uint64_t* h = c->res_host;
     CHK(input_errors(h + c->res_words));
     const uint64_t nch = l.n_channels, nb = l.n_time_bins, cells = nch * l.n_mux * nb;
@@ -743,7 +759,7 @@ int ppqc_fetch_tables(ppqc_ctx* c, ppqc_tables* o) {
 int ppqc_finalize(ppqc_ctx* c, ppqc_tables* o) {
     CHK(ppqc_finalize_extremes(c));
     CHK(ppqc_finalize_tables(c));
-    CHK(ppqc_finalize_n50(c, nullptr, 0));
+    CHK(finalize_n50_impl(c, nullptr, 0, true));
     return ppqc_fetch_tables(c, o);
 }
 
@@ -822,7 +838,9 @@ int ppqc_sort_u32_device(ppqc_ctx* c, uint32_t* keys, uint64_t n) {
     if (n >= (1ull << 32)) return fail(PPQC_E_RANGE, "more than 2^32-1 keys");
     HIPCHK(hipSetDevice(c->device));
     CHK(ensure_sort32(c, n ? n : 1));
-    HIPCHK(sort_u32(keys, c->sk32_tmp, n, c->counts, 0xFu, c->stream));
+    const uint32_t* out = keys;
+    HIPCHK(sort_u32(keys, c->sk32_tmp, keys, n, c->counts, 0xFu, c->stream, &out));   // four passes end in `keys`
+    if (out != keys) HIPCHK(hipMemcpyAsync(keys, out, n * 4, hipMemcpyDeviceToDevice, c->stream));
     return PPQC_OK;
 }
 

@@ -94,6 +94,7 @@ hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s);
 // res = [n_zero sums (tables + select histogram) = 0 | nch1 max = 0 | nch1 min = INT64_MAX | tmin = INT64_MAX,
 //        tmax = INT64_MIN | n50, total = 0 | 4 words of select state = 0]
 hipError_t launch_init_results(uint64_t* res, uint64_t n_zero, uint64_t nch1, hipStream_t s);
+hipError_t launch_reset_errors(uint64_t* e, hipStream_t s);
 
 // time_mode 1 helpers
 hipError_t launch_mode1_keys(ReadArrays ra, uint64_t n, const TableParams& tp, const int64_t* tminmax, uint64_t* keys,
@@ -102,17 +103,24 @@ hipError_t launch_mode1_hours(ReadArrays ra, uint64_t n, const TableParams& tp, 
                               const uint32_t* sorted_vals, uint32_t* chan_start, uint32_t* first_desc,
                               hipStream_t s);
 
-// Hand-written LSD radix sort.  `tmp_*` are ping-pong buffers of n elements, `counts` has 256*(n_waves+1)+256 u32.
-// On return the sorted data is in keys (and vals).  byte_mask selects which key bytes are sorted on.
+// Hand-written LSD radix sort.  `counts` has 256*(n_waves+1)+256 u32; byte_mask selects which key bytes are sorted on.
+// sort_u32: the first pass reads `in`, later passes ping-pong between buf_a and buf_b (`in` may be buf_b: in place);
+// *out = the buffer that holds the sorted keys.  sort_u64_pairs sorts keys/vals in place (tmp_* are the ping-pong).
 uint64_t sort_count_words(uint64_t n);
-hipError_t sort_u32(uint32_t* keys, uint32_t* tmp_keys, uint64_t n, uint32_t* counts, uint32_t byte_mask,
-                    hipStream_t s);
+hipError_t sort_u32(const uint32_t* in, uint32_t* buf_a, uint32_t* buf_b, uint64_t n, uint32_t* counts,
+                    uint32_t byte_mask, hipStream_t s, const uint32_t** out);
+// The same with all four passes enqueued and skipped on the device from gate[0] >= every key: no host round trip.
+hipError_t sort_u32_gated(const uint32_t* in, uint32_t* buf_a, uint32_t* buf_b, uint64_t n, uint32_t* counts,
+                          const uint64_t* gate, hipStream_t s);
 hipError_t sort_u64_pairs(uint64_t* keys, uint64_t* tmp_keys, uint32_t* vals, uint32_t* tmp_vals, uint64_t n,
                           uint32_t* counts, uint32_t byte_mask, hipStream_t s);
 
 // N50 over ascending-sorted lengths: out[0] = n50, out[1] = total bases.  block_sums has n/2048 + 2 u64.
 uint64_t n50_block_words(uint64_t n);
 hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s);
+// after sort_u32_gated(in, buf_a, buf_b, .., gate): picks the buffer the sorted keys ended in from the same gate word
+hipError_t launch_n50_gated(const uint32_t* in, const uint32_t* buf_a, const uint32_t* buf_b, const uint64_t* gate,
+                            uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s);
 
 // Exact N50 by MSD radix select (multi-GPU path).  state = {prefix, weight of all longer keys}; sel = PPQC_N_SEL u64.
 // hist: sel[d] += sum of the lengths whose bits above `shift + nbits` equal the prefix and whose digit is d.

@@ -7,15 +7,20 @@
 //   hist    : per-wave 256-bin digit histogram in LDS            -> counts[digit][wave]
 //   scan    : one block per digit scans its row, then the scatter waves prefix the 256 digit totals themselves
 //   scatter : per 64 keys, ballot-based match-any gives each lane its rank among equal digits (wave64: 64-bit masks)
+#include <stdlib.h>
+
 #include "ppqc_internal.hpp"
 
 namespace ppqc {
 
 constexpr uint32_t kMaxSortWaves = 2048;
+constexpr int kSortUnroll = 8;
 
 static inline void sort_geometry(uint64_t n, uint32_t* nw, uint32_t* chunk) {
     uint64_t c = (n + kMaxSortWaves - 1) / kMaxSortWaves;
-    if (c < 2048) c = 2048;
+    uint64_t cmin = 512;   // measured on MI355X, 10^6 keys: whole step 3.51 ms with 2048, 3.47 with 1024, 3.42 with 512
+    if (const char* e = getenv("PPQC_SORT_MIN_CHUNK")) cmin = (uint64_t)atoi(e) >= 64 ? (uint64_t)atoi(e) : cmin;   // A/B knob
+    if (c < cmin) c = cmin;
     c = (c + 63) & ~63ull;
     *chunk = (uint32_t)c;
     *nw = (uint32_t)((n + c - 1) / c);
@@ -29,8 +34,10 @@ uint64_t sort_count_words(uint64_t n) {
 
 template <typename K>
 __global__ __launch_bounds__(256) void rs_hist_kernel(const K* __restrict__ keys, uint64_t n, int shift,
-                                                      uint32_t* __restrict__ counts, uint32_t NW, uint32_t chunk) {
+                                                      uint32_t* __restrict__ counts, uint32_t NW, uint32_t chunk,
+                                                      const uint64_t* __restrict__ gate) {
     __shared__ uint32_t h[4][256];
+    if (gate && shift && (gate[0] >> shift) == 0) return;   // device-gated pass: no key has a bit at or above `shift`
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const uint32_t w = blockIdx.x * 4 + wib;
     for (int d = lane; d < 256; d += 64) h[wib][d] = 0;
@@ -38,7 +45,19 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const K* __restrict__ keys
     if (w < NW) {
         const uint64_t base = (uint64_t)w * chunk;
         const uint64_t end = base + chunk < n ? base + chunk : n;
-        for (uint64_t i = base + lane; i < end; i += 64) atomicAdd(&h[wib][(uint32_t)(keys[i] >> shift) & 255u], 1u);
+        // eight independent loads in flight per lane: the chunk is walked by one wave, so without them every 64 keys
+        // would pay a full memory latency
+        for (uint64_t i0 = base + lane; i0 < end; i0 += 64 * kSortUnroll) {
+            K k[kSortUnroll];
+#pragma unroll
+            for (int j = 0; j < kSortUnroll; ++j) {
+                const uint64_t i = i0 + 64ull * j;
+                k[j] = i < end ? keys[i] : (K)0;
+            }
+#pragma unroll
+            for (int j = 0; j < kSortUnroll; ++j)
+                if (i0 + 64ull * j < end) atomicAdd(&h[wib][(uint32_t)(k[j] >> shift) & 255u], 1u);
+        }
     }
     __syncthreads();
     if (w < NW)
@@ -46,8 +65,10 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const K* __restrict__ keys
 }
 
 // Block d: exclusive scan of row d (NW entries) in place; row total -> counts[256*NW + d].
-__global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ counts, uint32_t NW) {
+__global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ counts, uint32_t NW, int shift,
+                                                      const uint64_t* __restrict__ gate) {
     __shared__ uint32_t part[256];
+    if (gate && shift && (gate[0] >> shift) == 0) return;
     const uint32_t d = blockIdx.x, t = threadIdx.x;
     uint32_t* row = counts + (uint64_t)d * NW;
     const uint32_t seg = (NW + 255) / 256;
@@ -70,8 +91,10 @@ template <typename K, bool HAS_VAL>
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const K* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                          K* __restrict__ okeys, uint32_t* __restrict__ ovals,
                                                          uint64_t n, int shift, const uint32_t* __restrict__ counts,
-                                                         uint32_t NW, uint32_t chunk) {
+                                                         uint32_t NW, uint32_t chunk,
+                                                         const uint64_t* __restrict__ gate) {
     __shared__ uint32_t base[4][256];
+    if (gate && shift && (gate[0] >> shift) == 0) return;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const uint32_t w = blockIdx.x * 4 + wib;
     if (w >= NW) return;   // whole waves leave; no block-level barrier below
@@ -96,67 +119,99 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const K* __restrict__ k
     const uint64_t b0 = (uint64_t)w * chunk;
     const uint64_t end = b0 + chunk < n ? b0 + chunk : n;
     const uint64_t lt = (1ull << lane) - 1ull;
-    for (uint64_t r0 = b0; r0 < end; r0 += 64) {
-        const uint64_t i = r0 + lane;
-        const bool valid = i < end;
-        const K key = valid ? keys[i] : (K)0;
-        const uint32_t d = (uint32_t)(key >> shift) & 255u;
-        uint64_t peers = __ballot(valid);
+    for (uint64_t q0 = b0; q0 < end; q0 += 64 * kSortUnroll) {
+        K kk[kSortUnroll];
+        uint32_t vv[kSortUnroll];
 #pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-            const bool one = (d >> bit) & 1u;
-            const uint64_t bm = __ballot(valid && one);
-            peers &= one ? bm : ~bm;
+        for (int j = 0; j < kSortUnroll; ++j) {   // loads of the next 512 keys in flight together
+            const uint64_t i = q0 + 64ull * j + lane;
+            kk[j] = i < end ? keys[i] : (K)0;
+            if (HAS_VAL) vv[j] = i < end ? vals[i] : 0u;
         }
-        const uint32_t rank = (uint32_t)__popcll(peers & lt);
-        if (valid) {
-            const uint32_t pos = base[wib][d] + rank;
-            okeys[pos] = key;
-            if (HAS_VAL) ovals[pos] = vals[i];
+#pragma unroll
+        for (int j = 0; j < kSortUnroll; ++j) {
+            const uint64_t i = q0 + 64ull * j + lane;
+            if (q0 + 64ull * j >= end) break;   // wave-uniform
+            const bool valid = i < end;
+            const K key = kk[j];
+            const uint32_t d = (uint32_t)(key >> shift) & 255u;
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool one = (d >> bit) & 1u;
+                const uint64_t bm = __ballot(valid && one);
+                peers &= one ? bm : ~bm;
+            }
+            const uint32_t rank = (uint32_t)__popcll(peers & lt);
+            if (valid) {
+                const uint32_t pos = base[wib][d] + rank;
+                okeys[pos] = key;
+                if (HAS_VAL) ovals[pos] = vv[j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0) base[wib][d] += (uint32_t)__popcll(peers);
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) base[wib][d] += (uint32_t)__popcll(peers);
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
 template <typename K, bool HAS_VAL>
-static hipError_t radix_sort(K* keys, K* tmp_keys, uint32_t* vals, uint32_t* tmp_vals, uint64_t n, uint32_t* counts,
-                             uint32_t byte_mask, hipStream_t s) {
+static hipError_t radix_sort(const K* in, K* buf_a, K* buf_b, const uint32_t* vin, uint32_t* va, uint32_t* vb,
+                             uint64_t n, uint32_t* counts, uint32_t byte_mask, hipStream_t s, const K** out,
+                             const uint32_t** vout, const uint64_t* gate = nullptr) {
+    *out = in;
+    if (vout) *vout = vin;
     if (n < 2) return hipSuccess;
     if (n >= (1ull << 32)) return hipErrorInvalidValue;
     uint32_t NW, chunk;
     sort_geometry(n, &NW, &chunk);
     const unsigned blocks = (NW + 3) / 4;
-    K* src = keys; K* dst = tmp_keys;
-    uint32_t* vsrc = vals; uint32_t* vdst = tmp_vals;
+    const K* src = in; K* dst = buf_a;
+    const uint32_t* vsrc = vin; uint32_t* vdst = va;
     for (int byte = 0; byte < (int)sizeof(K); ++byte) {
         if (!((byte_mask >> byte) & 1u)) continue;
         const int shift = 8 * byte;
-        hipLaunchKernelGGL((rs_hist_kernel<K>), dim3(blocks), dim3(256), 0, s, src, n, shift, counts, NW, chunk);
-        hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, s, counts, NW);
+        hipLaunchKernelGGL((rs_hist_kernel<K>), dim3(blocks), dim3(256), 0, s, src, n, shift, counts, NW, chunk, gate);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, s, counts, NW, shift, gate);
         hipLaunchKernelGGL((rs_scatter_kernel<K, HAS_VAL>), dim3(blocks), dim3(256), 0, s, src, vsrc, dst, vdst, n,
-                           shift, counts, NW, chunk);
-        K* tk = src; src = dst; dst = tk;
-        uint32_t* tv = vsrc; vsrc = vdst; vdst = tv;
+                           shift, counts, NW, chunk, gate);
+        src = dst; vsrc = vdst;
+        dst = dst == buf_a ? buf_b : buf_a;
+        vdst = vdst == va ? vb : va;
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (src != keys) {
-        e = hipMemcpyAsync(keys, src, n * sizeof(K), hipMemcpyDeviceToDevice, s);
-        if (e != hipSuccess) return e;
-        if (HAS_VAL) e = hipMemcpyAsync(vals, vsrc, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
-    }
-    return e;
+    *out = src;
+    if (vout) *vout = vsrc;
+    return hipGetLastError();
 }
 
-hipError_t sort_u32(uint32_t* keys, uint32_t* tmp_keys, uint64_t n, uint32_t* counts, uint32_t byte_mask,
-                    hipStream_t s) {
-    return radix_sort<uint32_t, false>(keys, tmp_keys, nullptr, nullptr, n, counts, byte_mask & 0xFu, s);
+hipError_t sort_u32(const uint32_t* in, uint32_t* buf_a, uint32_t* buf_b, uint64_t n, uint32_t* counts,
+                    uint32_t byte_mask, hipStream_t s, const uint32_t** out) {
+    return radix_sort<uint32_t, false>(in, buf_a, buf_b, nullptr, nullptr, nullptr, n, counts, byte_mask & 0xFu, s, out,
+                                       nullptr);
+}
+// All four byte passes are enqueued, and each decides on the device whether it runs: pass p > 0 is skipped when
+// gate[0] (an upper bound of the keys, e.g. the max length left by the extremes kernel) has no bit at or above 8p.
+// The passes that run are 0..top, so the buffer roles are static (in -> a -> b -> a -> b) and the sorted keys end in
+// buf_a when top is even, else buf_b: launch_n50_gated makes the same choice from the same word.  No host round trip.
+hipError_t sort_u32_gated(const uint32_t* in, uint32_t* buf_a, uint32_t* buf_b, uint64_t n, uint32_t* counts,
+                          const uint64_t* gate, hipStream_t s) {
+    const uint32_t* out = nullptr;
+    return radix_sort<uint32_t, false>(in, buf_a, buf_b, nullptr, nullptr, nullptr, n, counts, 0xFu, s, &out, nullptr,
+                                       gate);
 }
 hipError_t sort_u64_pairs(uint64_t* keys, uint64_t* tmp_keys, uint32_t* vals, uint32_t* tmp_vals, uint64_t n,
                           uint32_t* counts, uint32_t byte_mask, hipStream_t s) {
-    return radix_sort<uint64_t, true>(keys, tmp_keys, vals, tmp_vals, n, counts, byte_mask & 0xFFu, s);
+    const uint64_t* ok = nullptr;
+    const uint32_t* ov = nullptr;
+    hipError_t e = radix_sort<uint64_t, true>(keys, tmp_keys, keys, vals, tmp_vals, vals, n, counts, byte_mask & 0xFFu,
+                                              s, &ok, &ov);
+    if (e != hipSuccess) return e;
+    if (ok != keys) {   // odd number of passes: bring the result home
+        e = hipMemcpyAsync(keys, ok, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(vals, ov, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+    }
+    return e;
 }
 
 // ---- N50 over ascending-sorted lengths -----------------------------------------------------------------------------
@@ -166,8 +221,22 @@ constexpr int kN50Block = 256 * kN50Items;
 
 uint64_t n50_block_words(uint64_t n) { return (n + kN50Block - 1) / kN50Block + 2; }
 
-__global__ __launch_bounds__(256) void n50_blocksum_kernel(const uint32_t* __restrict__ s, uint64_t n,
+// Which buffer holds the sorted keys after a gated sort (see sort_u32_gated); without a gate it is `a`.
+__device__ __forceinline__ const uint32_t* gated_pick(const uint32_t* a, const uint32_t* b, const uint64_t* gate,
+                                                      const uint32_t* in, uint64_t n) {
+    if (!gate) return a;
+    if (n < 2) return in;   // radix_sort enqueues nothing for fewer than two keys
+    const uint64_t m = gate[0];
+    const int top = m < (1ull << 8) ? 0 : (m < (1ull << 16) ? 1 : (m < (1ull << 24) ? 2 : 3));
+    return (top & 1) ? b : a;
+}
+
+__global__ __launch_bounds__(256) void n50_blocksum_kernel(const uint32_t* __restrict__ sa,
+                                                           const uint32_t* __restrict__ sb,
+                                                           const uint64_t* __restrict__ gate,
+                                                           const uint32_t* __restrict__ in, uint64_t n,
                                                            uint64_t* __restrict__ bsum) {
+    const uint32_t* __restrict__ s = gated_pick(sa, sb, gate, in, n);
     __shared__ unsigned long long acc;
     if (threadIdx.x == 0) acc = 0;
     __syncthreads();
@@ -205,8 +274,12 @@ __global__ __launch_bounds__(256) void n50_scan_kernel(uint64_t* __restrict__ bs
     for (uint64_t i = e; i > b; --i) { const uint64_t v = bsum[i - 1]; bsum[i - 1] = run; run += v; }
 }
 
-__global__ __launch_bounds__(256) void n50_find_kernel(const uint32_t* __restrict__ s, uint64_t n,
+__global__ __launch_bounds__(256) void n50_find_kernel(const uint32_t* __restrict__ sa,
+                                                       const uint32_t* __restrict__ sb,
+                                                       const uint64_t* __restrict__ gate,
+                                                       const uint32_t* __restrict__ in, uint64_t n,
                                                        const uint64_t* __restrict__ bsuf, uint64_t* __restrict__ out) {
+    const uint32_t* __restrict__ s = gated_pick(sa, sb, gate, in, n);
     __shared__ uint64_t part[256];
     const uint64_t total = out[1];
     if (total == 0) return;
@@ -234,13 +307,21 @@ __global__ __launch_bounds__(256) void n50_find_kernel(const uint32_t* __restric
     }
 }
 
-hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
+static hipError_t n50_launch(const uint32_t* sa, const uint32_t* sb, const uint64_t* gate, const uint32_t* in,
+                             uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
     if (n == 0) return hipMemsetAsync(out, 0, 16, s);
     const uint64_t nblocks = (n + kN50Block - 1) / kN50Block;
-    hipLaunchKernelGGL(n50_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sorted, n, block_sums);
+    hipLaunchKernelGGL(n50_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sa, sb, gate, in, n, block_sums);
     hipLaunchKernelGGL(n50_scan_kernel, dim3(1), dim3(256), 0, s, block_sums, nblocks, out);
-    hipLaunchKernelGGL(n50_find_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sorted, n, block_sums, out);
+    hipLaunchKernelGGL(n50_find_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sa, sb, gate, in, n, block_sums, out);
     return hipGetLastError();
+}
+hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
+    return n50_launch(sorted, nullptr, nullptr, sorted, n, block_sums, out, s);
+}
+hipError_t launch_n50_gated(const uint32_t* in, const uint32_t* buf_a, const uint32_t* buf_b, const uint64_t* gate,
+                            uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
+    return n50_launch(buf_a, buf_b, gate, in, n, block_sums, out, s);
 }
 
 // ---- N50 by weighted radix select (multi-GPU: only PPQC_N_SEL-word histograms cross xGMI) --------------------------

@@ -271,6 +271,16 @@ hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const u
     return hipGetLastError();
 }
 
+// the four input-error words behind the results: [0] bad CSR rows, [1] bad FASTQ records, [2] first of them, [3] bad
+// quality bytes
+__global__ void reset_errors_kernel(uint64_t* e) {
+    if (threadIdx.x < 4) e[threadIdx.x] = threadIdx.x == 2 ? ~0ull : 0ull;
+}
+hipError_t launch_reset_errors(uint64_t* e, hipStream_t s) {
+    hipLaunchKernelGGL(reset_errors_kernel, dim3(1), dim3(64), 0, s, e);
+    return hipGetLastError();
+}
+
 __global__ void init_results_kernel(uint64_t* res, uint64_t n_sum, uint64_t nch1) {
     const uint64_t total = n_sum + 2 * nch1 + 8;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {

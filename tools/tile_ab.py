@@ -1,6 +1,6 @@
 """A/B of tile-kernel variants in ONE process, interleaved rounds (guide rule 24). GPU box only.
 usage: python tools/tile_ab.py [reads] [rounds]"""
-import os, sys, json
+import os, sys, json, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,6 +12,8 @@ variants = os.environ.get("AB_VARIANTS", "0,1,2,3,4,5").split(",")
 bpcs = os.environ.get("AB_BPC", "0").split(",")
 shifts = os.environ.get("AB_SHIFT", "16").split(",")
 workload = os.environ.get("AB_WORKLOAD", "config2")
+sleep_ms = float(os.environ.get("AB_SLEEP_MS", "0"))
+tail = int(os.environ.get("AB_TAIL", "0"))
 seed = 20240601
 if workload == "adv":
     lens = synth.adversarial_lengths(reads, seed)
@@ -37,8 +39,10 @@ for rnd in range(rounds + 1):
             os.environ["PPQC_TILE_BLOCKS_PER_CU"] = bpc
             os.environ["PPQC_TILE_SHIFT"] = sh
             ctx.reset(); ctx.reset_timings()
+            if sleep_ms: time.sleep(sleep_ms / 1e3)      # idle gap before the launch (clock / DPM effects)
             ctx.submit_device(R, nb, db.data_ptr(), dq.data_ptr(), *[x.data_ptr() for x in d])
             tm = ctx.timings()
+            if tail: ctx.finalize()                       # the step tail of bench.py in front of the next tile kernel
             if rnd == 0:
                 s = ctx.read_stats(0, min(R, 20000))
                 sig = (int(s["gc"].sum()), int(s["qsum"].sum()), int(s["err_lo"].sum() & 0xFFFFFFFFFFFF), int(s["n"].sum()))
