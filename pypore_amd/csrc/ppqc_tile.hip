@@ -8,9 +8,11 @@
 // sweeps it in 1 KiB spans: lane l loads the 16 bytes at span + 16*l of each stream (global_load_dwordx4, 1 KiB
 // contiguous per wave instruction, always 16-byte aligned whatever the read boundaries are).  Read boundaries are
 // wave-uniform scalars walked along the offsets array.  A span that lies inside one read takes the fast path (SWAR byte
-// classification, v_sad_u8 byte sums, a 256-entry fixed-point LUT in LDS for 10^(-q/10)).  A span that contains read
-// boundaries evaluates, per boundary, one prefix-masked pass F(x) = sums over the first x bytes of the lane's vector;
-// segment sums are differences of prefixes (all quantities are integers, so this is exact).  Ultra-long reads are
+// classification, v_sad_u8 byte sums, a 256-entry fixed-point LUT in LDS for 10^(-q/10)).  A read boundary cuts exactly
+// one lane's vectors: the other lanes add their fast-path sums under a lane mask and the cut lane's 32 bytes are
+// classified one byte per lane (boundaries_bytepar); batches of very short reads take a second instantiation that
+// handles all boundaries of a span in one pass (boundary_rounds).  All quantities are integers, so every
+// decomposition gives the same sums.  Ultra-long reads are
 // thereby split over as many wavefronts as they have tiles; each wave writes a head/tail partial per tile and
 // finalize_reads merges them in tile order.  Everything is integer, so results do not depend on the decomposition.
 #include <stdlib.h>
@@ -82,31 +84,8 @@ __device__ __forceinline__ Acc vec_sums_quals(const uint4& vq, const uint64_t* l
     return a;
 }
 
-// Sums over the first x (0..16) bytes of the lane's vectors, lean version for the long-read kernel (which must stay
-// within 128 VGPRs): per-word masks, LUT entries added under a predicate.
-__device__ __noinline__ Acc vec_prefix_lean(uint4 vb, uint4 vq, int x, const uint64_t* lut) {
-    Acc a{0, 0, 0, 0};
-    const uint32_t wb[4] = {vb.x, vb.y, vb.z, vb.w};
-    const uint32_t wq[4] = {vq.x, vq.y, vq.z, vq.w};
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        int k = x - 4 * w;
-        k = k < 0 ? 0 : (k > 4 ? 4 : k);
-        const uint32_t mask = (uint32_t)((1ull << (8 * k)) - 1ull);
-        bases_word(wb[w] & mask, a.gcs, a.n);
-        const uint32_t q = wq[w] & mask;
-        a.qb = __builtin_amdgcn_sad_u8(q, 0u, a.qb);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint64_t e = lut[(q >> (8 * j)) & 0xffu];
-            a.err += (j < k) ? e : 0ull;
-        }
-    }
-    return a;
-}
-
-// The same for the short-read / line-mode kernels: the bytes from x on are zeroed (a zero byte matches no
-// base class and adds nothing to the byte sum) and their LUT entries, lut[0] = 2^52 each, are taken off again.
+// Sums over the first x (0..16) bytes of the lane's vectors (VECB kernels): the bytes from x on are zeroed (a zero byte
+// matches no base class and adds nothing to the byte sum) and their LUT entries, lut[0] = 2^52 each, are taken off again.
 __device__ __noinline__ Acc vec_prefix(uint4 vb, uint4 vq, int x, const uint64_t* lut) {
     uint32_t m[4];
 #pragma unroll
@@ -134,11 +113,20 @@ struct Walk {
     uint64_t r;    // current read
     uint64_t rs;   // its first byte
     uint64_t re;   // one past its last byte
+    uint64_t re2;  // SOFF: offsets[min(r + 2, R)], requested one read ahead through the scalar cache
     bool done;     // no read left
     // window of upcoming read ends, one per lane: lane i holds offsets[win_r0 + 1 + i] (the end of read win_r0 + i)
     uint64_t win, win_r0;
     bool win_ok;
 };
+
+// Wave-uniform read of offsets[idx] through the scalar data cache (s_load_dwordx2: its own counter and path, so a read
+// boundary neither queues behind the wave's streaming loads nor waits for its record stores).  Read-only: the
+// offsets are never written by this kernel.
+typedef const __attribute__((address_space(4))) uint64_t* const_u64_ptr;
+__device__ __forceinline__ uint64_t sload_u64(const uint64_t* p, uint64_t idx) {
+    return ((const_u64_ptr)(uintptr_t)p)[idx];
+}
 
 // Largest r in [0, R) with off[r] <= pos (pos < off[R]); 64-ary search, one probe per lane per round.
 __device__ __forceinline__ uint64_t find_read(const uint64_t* __restrict__ off, uint64_t R, uint64_t pos, int lane) {
@@ -194,10 +182,24 @@ __device__ __forceinline__ uint64_t read_end(Walk& w, const TileCtx& c, uint64_t
     return readlane_u64(w.win, (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r - w.win_r0)));
 }
 
-template <bool WIN>
+template <bool WIN, bool SOFF = false>
 __device__ __forceinline__ void walk_advance(Walk& w, const TileCtx& c) {
     w.rs = w.re;
     uint64_t r = w.r + 1;
+    if (SOFF) {
+        uint64_t e = w.re2;   // offsets[r + 1] of the new r, requested when the previous read began
+        while (r < c.R && e == w.rs) {   // skip empty reads
+            ++r;
+            if (r < c.R) e = sload_u64(c.off, r + 1);
+        }
+        w.r = r;
+        w.done = r >= c.R;
+        if (!w.done) {
+            w.re = e;
+            w.re2 = sload_u64(c.off, r + 2 < c.R ? r + 2 : c.R);
+        }
+        return;
+    }
     while (r < c.R) {
         const uint64_t e = WIN ? read_end(w, c, r) : uniform_u64(c.off[r + 1]);
         if (e != w.rs) { w.re = e; break; }   // skip empty reads
@@ -214,6 +216,74 @@ __device__ __forceinline__ void flush_read(Acc& acc, const Walk& w, const TileCt
     const uint64_t ri = c.read_base + w.r;
     flush(acc, c.lane, whole ? &c.ra.rec_cnt[ri] : &p->cnt, whole ? &c.ra.rec_hi[ri] : &p->hi,
           whole ? &c.ra.rec_lo[ri] : &p->lo);
+}
+
+// The boundaries of a span one after the other, with the byte-masked part done byte-parallel (the default kernel).
+// A read boundary cuts exactly ONE lane's 16-byte vectors (lane lb, at byte o); every other lane of the span belongs
+// to one read entirely and contributes its fast-path sums `tot` under a lane mask.  Lane lb's 32 bytes go through LDS
+// to lanes 0..31, one byte each (0..15: bases, 16..31: quality bytes); each of them classifies its byte with the same
+// formulas as the fast path (so the results are identical by construction) and adds it to its own running sums when
+// the byte lies on the ending read's side of the cut -- the wave reduction that a finished read needs anyway then
+// brings everything together.  The bytes behind the cut start the next read's sums the same way.  It replaced a
+// prefix-masked pass over all 64 lanes per boundary (375 vector instructions per boundary by SQ_INSTS_VALU, 22 % of
+// config 2's vector instructions); together with the scalar look-ahead of the offsets (walk_advance) the tile kernel
+// went from 5.6 to 6.3 TB/s at a mean read length of 5 kb and from 4.4 to 5.4 TB/s at 2.5 kb (tools/tile_ab.py).
+struct CutBytes { uint32_t gcs, n, qb; uint64_t err; };
+
+__device__ __noinline__ CutBytes cut_lane_bytes(uint4 vb, uint4 vq, int lb, int lane, uint32_t* xs, const uint64_t* lut) {
+    __builtin_amdgcn_wave_barrier();
+    if (lane == lb) {
+        *reinterpret_cast<uint4*>(xs) = vb;
+        *reinterpret_cast<uint4*>(xs + 4) = vq;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t bv = reinterpret_cast<const uint8_t*>(xs)[lane & 31];
+    __builtin_amdgcn_wave_barrier();
+    CutBytes r{0, 0, 0, 0};
+    bases_word(lane < 16 ? bv : 0u, r.gcs, r.n);   // a zero byte matches no class
+    const bool isq = lane >= 16 && lane < 32;
+    const uint64_t e = lut[bv];
+    r.qb = isq ? bv : 0u;
+    r.err = isq ? e : 0ull;
+    return r;
+}
+
+__device__ __forceinline__ void boundaries_bytepar(const uint4& vb, const uint4& vq, const Acc& tot, uint64_t span_base,
+                                                   uint64_t span_end, Walk& w, Acc& acc, const TileCtx& c) {
+    int prev_lb = -1, o_prev = 0;   // lane and byte offset of the last cut handled in this span
+    const int jj = c.lane & 15;
+    const bool low32 = c.lane < 32;
+    CutBytes cb{0, 0, 0, 0};
+    do {
+        const int x = (int)(uint32_t)(w.re - span_base);   // 0 .. kSpan-1, wave-uniform
+        const int lb = x >> 4, o = x & 15;
+        if (lb == prev_lb) {
+            // the read began in this very vector: it is bytes [o_prev, o) of lane lb, nothing else (cb is still valid)
+            const bool in = low32 && jj >= o_prev && jj < o;
+            acc.gcs = in ? cb.gcs : 0u; acc.n = in ? cb.n : 0u; acc.qb = in ? cb.qb : 0u; acc.err = in ? cb.err : 0ull;
+        } else {
+            if (c.lane > prev_lb && c.lane < lb) acc_add(acc, tot);
+            if (o) {
+                cb = cut_lane_bytes(vb, vq, lb, c.lane, c.xs, c.lut);
+                if (low32 && jj < o) { acc.gcs += cb.gcs; acc.n += cb.n; acc.qb += cb.qb; acc.err += cb.err; }
+            }
+        }
+        flush_read(acc, w, c);   // acc = 0
+        walk_advance<false, true>(w, c);
+        if (o) {   // the next read owns the bytes of lane lb behind the cut
+            if (low32 && jj >= o) { acc.gcs = cb.gcs; acc.n = cb.n; acc.qb = cb.qb; acc.err = cb.err; }
+            prev_lb = lb; o_prev = o;
+        } else {   // cut on a vector boundary: lane lb goes in whole with the lanes behind it
+            prev_lb = lb - 1; o_prev = 0;
+        }
+    } while (!w.done && w.re < span_end);
+    if (!w.done) {
+        if (c.lane > prev_lb) acc_add(acc, tot);   // the rest of the span belongs to the open read
+        if (w.re == span_end) {
+            flush_read(acc, w, c);
+            walk_advance<false, true>(w, c);
+        }
+    }
 }
 
 // A span that contains read boundaries, all of them at once.  Lane i of the offsets window owns the read that ends at
@@ -318,17 +388,19 @@ __device__ __forceinline__ void process_span(const uint4& vb, const uint4& vq, u
         acc_add(acc, tot);
         if (w.re == span_end) {
             flush_read(acc, w, c);
-            walk_advance<VECB>(w, c);
+            walk_advance<VECB, !VECB>(w, c);
         }
+    } else if (!VECB) {
+        boundaries_bytepar(vb, vq, tot, c.tile_start + span_rel, span_end, w, acc, c);
     } else {
         // one or more reads end strictly inside this span (or the data ends inside it)
         Acc prev{0, 0, 0, 0};
         const int vrel = (int)(span_rel + c.lane_off);
-        const bool finished = VECB && boundary_rounds(vb, vq, tot, c.tile_start + span_rel, span_end, w, acc, prev, c);
+        const bool finished = boundary_rounds(vb, vq, tot, c.tile_start + span_rel, span_end, w, acc, prev, c);
         if (!finished && !w.done && w.re < span_end) do {
             int x = (int)(uint32_t)(w.re - c.tile_start) - vrel;
             x = x < 0 ? 0 : (x > kVec ? kVec : x);
-            const Acc f = VECB ? vec_prefix(vb, vq, x, c.lut) : vec_prefix_lean(vb, vq, x, c.lut);
+            const Acc f = vec_prefix(vb, vq, x, c.lut);
             acc_add(acc, acc_sub(f, prev));
             prev = f;
             flush_read(acc, w, c);
@@ -414,6 +486,8 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
         w.done = false;
         w.win = 0; w.win_r0 = 0; w.win_ok = false;
         w.re = VECB ? read_end(w, c, w.r) : uniform_u64(c.off[w.r + 1]);
+        w.re2 = 0;
+        if (!VECB) w.re2 = sload_u64(c.off, w.r + 2 < c.R ? w.r + 2 : c.R);
         Acc acc{0, 0, 0, 0};
 
         if (PIPE) {
@@ -438,13 +512,14 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
     }
 }
 
-// VECB: read boundaries of a span handled all at once (boundary_rounds) instead of one masked pass each.  It costs 16
-// VGPRs (144 instead of 128: 3 instead of 4 waves per SIMD), so it is a separate instantiation that the launcher picks
-// for batches of short reads, where boundaries dominate; long reads keep the leaner kernel.
+// VECB: read boundaries of a span handled all at once (boundary_rounds) instead of one after the other.  It needs 158
+// VGPRs (3 instead of 4 waves per SIMD) and its fast path is slower, so it is a separate instantiation that the
+// launcher picks for batches of very short reads (mean below kVecbMeanLen bytes), where several reads end in most spans.
 template <int NB, bool NT, bool PIPE, bool VECB>
-__global__ __launch_bounds__(256) void tile_kernel(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra,
-                                                   uint64_t read_base, Partial* __restrict__ head,
-                                                   Partial* __restrict__ tail, uint64_t n_tiles) {
+__global__ __launch_bounds__(256, (VECB ? 3 : 4)) void tile_kernel(BatchView b, const uint64_t* __restrict__ lut_g,
+                                                                  ReadArrays ra, uint64_t read_base,
+                                                                  Partial* __restrict__ head, Partial* __restrict__ tail,
+                                                                  uint64_t n_tiles) {
     tile_body<NB, NT, PIPE, false, VECB>(b, lut_g, ra, read_base, head, tail, n_tiles);
 }
 
@@ -507,7 +582,7 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
     ra.time[g] = b.time[i];
 }
 
-constexpr uint64_t kVecbMeanLen = 1280;   // mean read length (bytes) below which the VECB kernel is launched
+constexpr uint64_t kVecbMeanLen = 448;   // mean read length (bytes) below which the VECB kernel is launched
 
 template <int NB, bool NT, bool PIPE, bool LINE = false, bool VECB = false>
 static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
@@ -541,20 +616,12 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
     const int bpc = bp ? atoi(bp) : 0;
     const int variant = v ? atoi(v) : 0;
     switch (variant) {
-        case 1: return launch_tile_variant<4, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-        case 2: return launch_tile_variant<8, false, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
         case 3: return launch_tile_variant<8, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-        case 4: return launch_tile_variant<4, true, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-        case 5: return launch_tile_variant<2, true, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-        case 6: return launch_tile_variant<6, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-        case 10: return launch_tile_variant<10, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-        case 12: return launch_tile_variant<12, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-        case 106: return launch_tile_variant<6, true, false, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+        case 2: return launch_tile_variant<8, false, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
         case 108: return launch_tile_variant<8, true, false, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-        case 110: return launch_tile_variant<10, true, false, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
         default: {
-            // short reads: boundaries dominate, take the kernel that handles them wave-parallel (threshold measured,
-            // see DESIGN.md); PPQC_TILE_VECB=0|1 forces one of them for A/B runs
+            // very short reads: several boundaries per span, take the kernel that handles them all at once
+            // (threshold measured); PPQC_TILE_VECB=0|1 forces one of them for A/B runs
             const char* vb = getenv("PPQC_TILE_VECB");
             const bool vecb = vb ? atoi(vb) != 0 : b.n_bytes / b.n_reads < kVecbMeanLen;
             if (vecb) return launch_tile_variant<8, true, false, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);

@@ -1,0 +1,79 @@
+// Ceiling of the tile kernel's access pattern: two byte streams, one wave per 64 KiB tile of each, 16-byte nontemporal
+// loads, 16 loads in flight per lane, almost no arithmetic (xor-reduce).  Build: hipcc --offload-arch=gfx950 -O3 -o
+// tools/micro/hbm_read_peak tools/micro/hbm_read_peak.hip ; run on the GPU box: tools/micro/hbm_read_peak [GB per stream]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NB, bool NT>
+__global__ __launch_bounds__(256) void read_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                   uint64_t n_tiles, uint32_t* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t t = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const uint8_t* pa = a + (t << 16) + lane * 16;
+    const uint8_t* pb = b + (t << 16) + lane * 16;
+    u32x4 acc = {0, 0, 0, 0};
+    for (int s0 = 0; s0 < 64; s0 += NB) {
+        u32x4 va[NB], vb[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (NT) {
+                va[i] = __builtin_nontemporal_load((const u32x4*)(pa + (s0 + i) * 1024));
+                vb[i] = __builtin_nontemporal_load((const u32x4*)(pb + (s0 + i) * 1024));
+            } else {
+                va[i] = *(const u32x4*)(pa + (s0 + i) * 1024);
+                vb[i] = *(const u32x4*)(pb + (s0 + i) * 1024);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) acc ^= va[i] ^ vb[i];
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;   // keeps the loads alive
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+template <int NB, bool NT>
+static int run(const char* name, const uint8_t* a, const uint8_t* b, uint64_t n_tiles, uint32_t* sink) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const unsigned blocks = (unsigned)((n_tiles + 3) / 4);
+    float best = 1e9f, sum = 0.f;
+    const int reps = 7;
+    for (int r = 0; r < reps + 1; ++r) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((read_kernel<NB, NT>), dim3(blocks), dim3(256), 0, 0, a, b, n_tiles, sink);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r) { best = ms < best ? ms : best; sum += ms; }
+    }
+    const double bytes = 2.0 * (double)n_tiles * 65536.0;
+    printf("%-28s mean %.3f ms  %.0f GB/s   best %.3f ms  %.0f GB/s\n", name, sum / reps, bytes / (sum / reps) / 1e6, best,
+           bytes / best / 1e6);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const double gb = argc > 1 ? atof(argv[1]) : 9.95;
+    const uint64_t n_tiles = (uint64_t)(gb * 1e9) >> 16;
+    const uint64_t n = n_tiles << 16;
+    uint8_t *a, *b;
+    uint32_t* sink;
+    CK(hipMalloc((void**)&a, n)); CK(hipMalloc((void**)&b, n)); CK(hipMalloc((void**)&sink, 64));
+    CK(hipMemset(a, 1, n)); CK(hipMemset(b, 2, n)); CK(hipMemset(sink, 0, 64));
+    CK(hipDeviceSynchronize());
+    printf("2 streams x %.2f GB, one wave per 64 KiB tile\n", n / 1e9);
+    for (int rep = 0; rep < 2; ++rep) {
+        if (run<8, true>("16 loads in flight, nt", a, b, n_tiles, sink)) return 1;
+        if (run<8, false>("16 loads in flight, temporal", a, b, n_tiles, sink)) return 1;
+        if (run<4, true>("8 loads in flight, nt", a, b, n_tiles, sink)) return 1;
+        if (run<16, true>("32 loads in flight, nt", a, b, n_tiles, sink)) return 1;
+    }
+    return 0;
+}

@@ -19,6 +19,9 @@ if workload == "adv":
     lens = synth.adversarial_lengths(reads, seed)
 elif workload == "config4":
     lens = synth.read_lengths(reads, 10.1266, 1.1774, seed)
+elif workload.startswith("mean"):   # e.g. mean300: lognormal with that mean length (sigma 1.1774: mean = 2 e^mu)
+    import math
+    lens = synth.read_lengths(reads, math.log(float(workload[4:]) / 2.0), 1.1774, seed)
 elif workload == "short":
     lens = synth.read_lengths(reads, 6.0, 1.0, seed)
 else:
