@@ -241,7 +241,12 @@ int ppqc_set_ref_time(ppqc_ctx* ctx, int64_t ref_time);
 int ppqc_finalize_tables(ppqc_ctx* ctx);
 int ppqc_finalize_n50(ppqc_ctx* ctx, const uint32_t* device_lengths, uint64_t n);
 int ppqc_fetch_tables(ppqc_ctx* ctx, ppqc_tables* out);
+/* The same without the copy: the table pointers of `out` are SET to point into the context's pinned host result
+ * buffer (read-only for the caller; overwritten by the next fetch, released by ppqc_destroy).  For callers that consume
+ * the tables at once, like the loop of FastStats over ChannelDict (lib/seq_routines.py:97-144). */
+int ppqc_fetch_tables_view(ppqc_ctx* ctx, ppqc_tables* out);
 int ppqc_finalize(ppqc_ctx* ctx, ppqc_tables* out);
+int ppqc_finalize_view(ppqc_ctx* ctx, ppqc_tables* out);   /* ppqc_finalize ending in ppqc_fetch_tables_view */
 int ppqc_device_tables_view(ppqc_ctx* ctx, ppqc_device_tables* out);
 
 /* Multi-GPU N50 without gathering the lengths (no reference counterpart): exact MSD radix SELECT of the

@@ -26,7 +26,7 @@ SYMBOLS = (
     "ppqc_last_error", "ppqc_abi_version", "ppqc_device_count", "ppqc_config_default", "ppqc_create",
     "ppqc_destroy", "ppqc_reset", "ppqc_alloc_pinned", "ppqc_free_pinned", "ppqc_submit", "ppqc_submit_device", "ppqc_submit_records",
     "ppqc_sync", "ppqc_n_reads", "ppqc_read_stats", "ppqc_read_hours", "ppqc_finalize_extremes",
-    "ppqc_finalize_tables", "ppqc_finalize_n50", "ppqc_fetch_tables", "ppqc_finalize", "ppqc_device_tables_view",
+    "ppqc_finalize_tables", "ppqc_finalize_n50", "ppqc_fetch_tables", "ppqc_fetch_tables_view", "ppqc_finalize", "ppqc_finalize_view", "ppqc_device_tables_view",
     "ppqc_timings", "ppqc_reset_timings", "ppqc_sort_u32_device", "ppqc_synth_fill_device", "ppqc_fastq_scan", "ppqc_fastq_pack",
     "ppqc_submit_fastq", "ppqc_submit_fastq_device", "ppqc_input_errors", "ppqc_time_range", "ppqc_set_ref_time", "ppqc_n50_select_hist", "ppqc_n50_select_pick", "ppqc_set_stream",
 )
@@ -128,7 +128,8 @@ def load():
         "ppqc_read_hours": [P, P, C.c_uint64, C.c_uint64],
         "ppqc_finalize_extremes": [P], "ppqc_finalize_tables": [P],
         "ppqc_finalize_n50": [P, P, C.c_uint64], "ppqc_fetch_tables": [P, C.POINTER(Tables)],
-        "ppqc_finalize": [P, C.POINTER(Tables)], "ppqc_device_tables_view": [P, C.POINTER(DeviceTables)],
+        "ppqc_finalize": [P, C.POINTER(Tables)], "ppqc_finalize_view": [P, C.POINTER(Tables)],
+        "ppqc_fetch_tables_view": [P, C.POINTER(Tables)], "ppqc_device_tables_view": [P, C.POINTER(DeviceTables)],
         "ppqc_timings": [P, C.POINTER(Timing)], "ppqc_reset_timings": [P],
         "ppqc_sort_u32_device": [P, P, C.c_uint64],
         "ppqc_synth_fill_device": [P, P, P, C.c_uint64, C.c_uint64, C.c_uint64],

@@ -719,7 +719,7 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
 
 int ppqc_finalize_n50(ppqc_ctx* c, const uint32_t* dlens, uint64_t n) { return finalize_n50_impl(c, dlens, n, false); }
 
-int ppqc_fetch_tables(ppqc_ctx* c, ppqc_tables* o) {
+static int fetch_tables_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
     if (!c || !o) return fail(PPQC_E_INVALID, "null argument");
     if (c->state < 3) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes/tables/n50 first");
     HIPCHK(hipSetDevice(c->device));
@@ -733,18 +733,19 @@ int ppqc_fetch_tables(ppqc_ctx* c, ppqc_tables* o) {
     const uint64_t* h = c->res_host;
     CHK(input_errors(h + c->res_words));
     const uint64_t nch = l.n_channels, nb = l.n_time_bins, cells = nch * l.n_mux * nb;
-#define OUT(dst, off, cnt) if (dst) memcpy(dst, h + (off), (cnt) * 8)
+    uint64_t* hv = c->res_host;
+#define OUT(dst, off, cnt) do { if (view) dst = hv + (off); else if (dst) memcpy(dst, h + (off), (cnt) * 8); } while (0)
     OUT(o->totals, l.off_totals, PPQC_N_TOTALS); OUT(o->len_hist_log2, l.off_len_log2, PPQC_N_LEN_LOG2);
     OUT(o->len_hist_lin, l.off_len_lin, PPQC_N_LEN_LIN); OUT(o->q_hist, l.off_q_hist, PPQC_N_QHIST);
     OUT(o->gc_hist, l.off_gc_hist, PPQC_N_GCHIST); OUT(o->hour_reads, l.off_hour_reads, nb);
     OUT(o->hour_bases, l.off_hour_bases, nb); OUT(o->chan_reads, l.off_chan_reads, nch);
     OUT(o->chan_bases, l.off_chan_bases, nch); OUT(o->chan_fail, l.off_chan_fail, nch);
     OUT(o->cmh_reads, l.off_cmh_reads, cells); OUT(o->cmh_bases, l.off_cmh_bases, cells);
-#undef OUT
     const uint64_t* mx = h + l.n_sum + PPQC_N_SEL;
     const uint64_t* mn = mx + 1 + nch;
-    if (o->chan_max_len) memcpy(o->chan_max_len, mx + 1, nch * 8);
-    if (o->chan_min_len) memcpy(o->chan_min_len, mn + 1, nch * 8);
+    OUT(o->chan_max_len, l.n_sum + PPQC_N_SEL + 1, nch);
+    OUT(o->chan_min_len, l.n_sum + PPQC_N_SEL + 1 + nch + 1, nch);
+#undef OUT
     o->max_len = mx[0];
     o->min_pos_len = mn[0];
     o->lin_bin_width = mx[0] / PPQC_N_LEN_LIN + 1;
@@ -756,12 +757,17 @@ int ppqc_fetch_tables(ppqc_ctx* c, ppqc_tables* o) {
     return PPQC_OK;
 }
 
-int ppqc_finalize(ppqc_ctx* c, ppqc_tables* o) {
+int ppqc_fetch_tables(ppqc_ctx* c, ppqc_tables* o) { return fetch_tables_impl(c, o, false); }
+int ppqc_fetch_tables_view(ppqc_ctx* c, ppqc_tables* o) { return fetch_tables_impl(c, o, true); }
+
+static int finalize_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
     CHK(ppqc_finalize_extremes(c));
     CHK(ppqc_finalize_tables(c));
     CHK(finalize_n50_impl(c, nullptr, 0, true));
-    return ppqc_fetch_tables(c, o);
+    return fetch_tables_impl(c, o, view);
 }
+int ppqc_finalize(ppqc_ctx* c, ppqc_tables* o) { return finalize_impl(c, o, false); }
+int ppqc_finalize_view(ppqc_ctx* c, ppqc_tables* o) { return finalize_impl(c, o, true); }
 
 int ppqc_device_tables_view(ppqc_ctx* c, ppqc_device_tables* o) {
     if (!c || !o) return fail(PPQC_E_INVALID, "null argument");

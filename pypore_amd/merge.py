@@ -37,7 +37,7 @@ def gather_lengths(lengths_t, dist, torch, group=None):
     return out
 
 
-def finalize_distributed(ctx, dist, torch, group=None, n50="select"):
+def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True):
     """Phased finalize of a QCContext with RCCL merges in between; returns the merged tables on every rank.
 
     The context is put on torch's current stream, so its kernels and the collectives (which torch orders against that
@@ -46,7 +46,8 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select"):
     ``n50="select"`` (default): exact N50 by weighted radix select -- three rounds, each a 2048-word histogram that is
     all-reduced (the first one rides along with the table buffer), so only small tables cross xGMI and the cost does
     not grow with the number of ranks.  ``n50="gather"``: all-gather the u32 lengths and run the LSD radix sort + N50
-    on every rank (the single-GPU algorithm; its sort grows with the whole job)."""
+    on every rank (the single-GPU algorithm; its sort grows with the whole job).  ``copy=False``: the tables are views
+    of the context's pinned result buffer (``QCContext.fetch_tables``)."""
     handle = torch.cuda.current_stream().cuda_stream
     if ctx.external_stream != handle:
         ctx.set_stream(handle)
@@ -67,7 +68,7 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select"):
             ctx.n50_select_hist(r)
             dist.all_reduce(t_sel, op=dist.ReduceOp.SUM, group=group)
             ctx.n50_select_pick(r)
-        return ctx.fetch_tables()
+        return ctx.fetch_tables(copy=copy)
     t_sum = torch.as_tensor(views["sum"], device="cuda")
     dist.all_reduce(t_sum, op=dist.ReduceOp.SUM, group=group)
     n_local = views["lengths"].__cuda_array_interface__["shape"][0]
@@ -77,7 +78,7 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select"):
         lens = torch.zeros(0, dtype=torch.int32, device="cuda")
     all_lens = gather_lengths(lens, dist, torch, group)
     ctx.finalize_n50(all_lens.data_ptr(), all_lens.numel())
-    tables = ctx.fetch_tables()                  # synchronises: all_lens may be released afterwards
+    tables = ctx.fetch_tables(copy=copy)         # synchronises: all_lens may be released afterwards
     return tables
 
 

@@ -184,8 +184,40 @@ class QCContext:
                    n50=int(t.n50))
         return out
 
-    def finalize(self):
-        """Single-GPU run-level tables (extremes -> tables -> radix sort + N50 -> fetch)."""
+    def _tables_view(self, t):
+        """Tables as zero-copy numpy views of the context's pinned host result buffer (filled by a *_view call)."""
+        if getattr(self, "_layout", None) is None:
+            d = L.DeviceTables()
+            L.check(self._lib.ppqc_device_tables_view(self._ctx, C.byref(d)))
+            self._layout = int(d.n_sum + d.n_sel + d.n_max + d.n_min + 8)
+            self._res_base, self._res = None, None
+        base = int(t.totals)
+        if self._res_base != base:
+            self._res = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_int64)), shape=(self._layout,))
+            self._res_base = base
+        nch, nmux, nb = self.cfg.n_channels, self.cfg.n_mux, self.cfg.n_time_bins
+        sizes = dict(totals=L.N_TOTALS, len_hist_log2=L.N_LEN_LOG2, len_hist_lin=L.N_LEN_LIN, q_hist=L.N_QHIST,
+                     gc_hist=L.N_GCHIST, hour_reads=nb, hour_bases=nb, chan_reads=nch, chan_bases=nch, chan_fail=nch,
+                     cmh_reads=nch * nmux * nb, cmh_bases=nch * nmux * nb, chan_min_len=nch, chan_max_len=nch)
+        out = {}
+        for k, n in sizes.items():
+            o = (int(getattr(t, k)) - base) // 8
+            out[k] = self._res[o:o + n]
+        out["cmh_reads"] = out["cmh_reads"].reshape(nch, nmux, nb)
+        out["cmh_bases"] = out["cmh_bases"].reshape(nch, nmux, nb)
+        out.update(max_len=int(t.max_len), min_pos_len=int(t.min_pos_len), lin_bin_width=int(t.lin_bin_width),
+                   n50=int(t.n50))
+        return out
+
+    def finalize(self, copy=True):
+        """Single-GPU run-level tables (extremes -> tables -> radix sort + N50 -> fetch).  ``copy=False`` returns views
+        of the context's pinned result buffer instead of fresh arrays: valid until the next finalize / fetch of this
+        context (for callers that consume the tables at once)."""
+        if not copy:
+            t = L.Tables()
+            L.check(self._lib.ppqc_finalize_view(self._ctx, C.byref(t)))
+            self._keep.clear()
+            return self._tables_view(t)
         arr, t = self._alloc_tables()
         L.check(self._lib.ppqc_finalize(self._ctx, C.byref(t)))
         self._keep.clear()
@@ -231,7 +263,11 @@ class QCContext:
         L.check(self._lib.ppqc_set_stream(self._ctx, None, 0))
         self.external_stream = None
 
-    def fetch_tables(self):
+    def fetch_tables(self, copy=True):
+        if not copy:
+            t = L.Tables()
+            L.check(self._lib.ppqc_fetch_tables_view(self._ctx, C.byref(t)))
+            return self._tables_view(t)
         arr, t = self._alloc_tables()
         L.check(self._lib.ppqc_fetch_tables(self._ctx, C.byref(t)))
         return self._tables_dict(arr, t)

@@ -357,6 +357,27 @@ def test_n50_radix_select_equals_sort(qc, c_oracle):
         assert_tables_equal(a, b)
 
 
+def test_table_views_equal_copies(qc):
+    """ppqc_finalize_view / ppqc_fetch_tables_view (pointers into the pinned result buffer) give the tables of
+    ppqc_finalize / ppqc_fetch_tables, on two runs in a row of one context (the second smaller)."""
+    cfg = dict(n_channels=64, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=0, tz_offset_s=0,
+               ref_time_s=1_528_000_000, fail_q=7.0)
+    with qc.QCContext(device=0, **cfg) as ctx:
+        for seed, n in ((5, 3000), (6, 700)):
+            b = random_batch(seed, n, 1500, n_channels=64)
+            ctx.reset()
+            ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], b["fail_flag"])
+            want = ctx.finalize()
+            ctx.reset()
+            ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], b["fail_flag"])
+            view = ctx.finalize(copy=False)
+            view2 = {k: (np.array(v) if isinstance(v, np.ndarray) else v) for k, v in view.items()}
+            assert_tables_equal(view2, want)
+            again = ctx.fetch_tables(copy=False)
+            assert all(np.array_equal(again[k], want[k]) for k in want)
+            assert int(want["totals"][0]) == n
+
+
 def test_malformed_device_csr_fails_loudly_without_faulting(qc):
     """A device batch cannot be validated on the host; bad offsets must neither fault nor pass."""
     import torch
