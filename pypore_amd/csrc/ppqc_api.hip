@@ -55,7 +55,8 @@ struct ppqc_ctx {
     TableParams tp{};
     hipStream_t stream = nullptr, own_stream = nullptr, copy[2] = {nullptr, nullptr};
     hipStream_t aux = nullptr;      // the sort + N50 chain runs here, beside the tables kernel on `stream`
-    hipEvent_t ev_join = nullptr;
+    hipEvent_t ev_join = nullptr, ev_init = nullptr, ev_tail = nullptr;
+    bool tail_recorded = false;   // ev_tail marks the end of the last finalize phase enqueued on `stream`
     uint64_t* lut_dev = nullptr;
 
     ReadArrays ra{};
@@ -176,6 +177,12 @@ static int input_errors(const uint64_t* e) {
     return PPQC_OK;
 }
 
+static int mark_tail(ppqc_ctx* c) {
+    HIPCHK(hipEventRecord(c->ev_tail, c->stream));
+    c->tail_recorded = true;
+    return PPQC_OK;
+}
+
 static uint64_t q_threshold(double q) { return (uint64_t)llrint(ldexp(pow(10.0, -q / 10.0), PPQC_ERR_SHIFT)); }
 
 static void make_layout(const ppqc_config& cfg, TableLayout* l) {
@@ -259,6 +266,8 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_max, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&c->maxlen_host, 64, hipHostMallocDefault));
 
     // error-probability LUT: e[b] = round(2^52 * 10^(-q/10)), q = clamp(b - 33, 0, 93)
@@ -315,6 +324,8 @@ int ppqc_destroy(ppqc_ctx* c) {
     if (c->maxlen_host) (void)hipHostFree(c->maxlen_host);
     if (c->ev_max) (void)hipEventDestroy(c->ev_max);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_init) (void)hipEventDestroy(c->ev_init);
+    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     for (int i = 0; i < 2; ++i) {
         Slot& s = c->slot[i];
@@ -627,12 +638,18 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     c->sum_fetched = false;
+    // The result buffer is cleared on the auxiliary stream: this call is usually enqueued while the per-read kernels of
+    // the batch still run, and nothing before the extremes kernel touches the results, so the clear costs no time on
+    // the main stream.  It only has to come after the last finalize phase that was enqueued before (ev_tail).
+    if (c->tail_recorded) HIPCHK(hipStreamWaitEvent(c->aux, c->ev_tail, 0));
+    HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, c->aux));
+    HIPCHK(hipEventRecord(c->ev_init, c->aux));
     HIPCHK(hipEventRecord(c->ev_t0, s));
-    HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, s));
+    HIPCHK(hipStreamWaitEvent(s, c->ev_init, 0));
     HIPCHK(launch_extremes(c->ra, c->n_reads, c->tp, c->max_buf, c->min_buf, c->tminmax, s));
     HIPCHK(hipEventRecord(c->ev_max, s));   // fork point of the sort + N50 chain (ppqc_finalize_n50)
     c->state = 1;
-    return PPQC_OK;
+    return mark_tail(c);
 }
 
 int ppqc_time_range(ppqc_ctx* c, int64_t* out2) {
@@ -680,7 +697,7 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
     }
     HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, c->max_buf, s));
     c->state = 2;
-    return PPQC_OK;
+    return mark_tail(c);
 }
 
 static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, bool early_fetch) {
@@ -714,7 +731,7 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     }
     HIPCHK(hipEventRecord(c->ev_t1, s));
     c->state = 3;
-    return PPQC_OK;
+    return mark_tail(c);
 }
 
 int ppqc_finalize_n50(ppqc_ctx* c, const uint32_t* dlens, uint64_t n) { return finalize_n50_impl(c, dlens, n, false); }
@@ -794,7 +811,7 @@ int ppqc_n50_select_hist(ppqc_ctx* c, int round) {
     if (round == 0) HIPCHK(hipEventRecord(c->ev_s0, c->stream));
     HIPCHK(launch_select_hist(c->ra.lens32, c->n_reads, kSelShift[round], kSelBits[round], c->sel_state, c->sel_buf,
                               c->stream));
-    return PPQC_OK;
+    return mark_tail(c);
 }
 
 int ppqc_n50_select_pick(ppqc_ctx* c, int round) {
@@ -809,7 +826,7 @@ int ppqc_n50_select_pick(ppqc_ctx* c, int round) {
         HIPCHK(hipEventRecord(c->ev_t1, c->stream));
         c->state = 3;
     }
-    return PPQC_OK;
+    return mark_tail(c);
 }
 
 int ppqc_set_stream(ppqc_ctx* c, void* stream, int use_external) {
