@@ -55,8 +55,10 @@ struct ppqc_ctx {
     TableParams tp{};
     hipStream_t stream = nullptr, own_stream = nullptr, copy[2] = {nullptr, nullptr};
     hipStream_t aux = nullptr;      // the sort + N50 chain runs here, beside the tables kernel on `stream`
-    hipEvent_t ev_join = nullptr, ev_init = nullptr, ev_tail = nullptr;
-    bool tail_recorded = false;   // ev_tail marks the end of the last finalize phase enqueued on `stream`
+    hipEvent_t ev_join = nullptr, ev_init = nullptr;
+    bool res_busy = false;   // a finalize phase (or a caller's collective on the tables) may still run: set by every
+                             // finalize phase, cleared when the stream has been synchronised
+    hipEvent_t last_a = nullptr, sort_end = nullptr;   // start event of the newest batch (submit_ms_last)
     uint64_t* lut_dev = nullptr;
 
     ReadArrays ra{};
@@ -73,6 +75,8 @@ struct ppqc_ctx {
              *sel_state = nullptr;
     int64_t* tminmax = nullptr;
     int state = 0;   // 0 reads only, 1 extremes done, 2 tables done, 3 n50 done
+    bool lens_early = true;    // every read of the run came through finalize_reads: lens32 and the sort gate are ready
+    hipEvent_t ev_reads = nullptr;   // behind the last finalize_reads of the run
     bool sum_fetched = false;   // ppqc_finalize: the SUM tables were copied to res_host behind the tables kernel
     uint64_t n50 = 0;
 
@@ -130,7 +134,7 @@ static int ensure_reads(ppqc_ctx* c, uint64_t need) {
     CHK(grow(&r.qsum, n, cap, s)); CHK(grow(&r.mean_q, n, cap, s));
     CHK(grow(&r.err_hi, n, cap, s)); CHK(grow(&r.err_lo, n, cap, s)); CHK(grow(&r.flags, n, cap, s));
     CHK(grow(&r.channel, n, cap, s)); CHK(grow(&r.mux, n, cap, s)); CHK(grow(&r.time, n, cap, s));
-    CHK(grow(&r.hour, 0, cap, s)); CHK(grow(&r.lens32, 0, cap, s));
+    CHK(grow(&r.hour, 0, cap, s)); CHK(grow(&r.lens32, n, cap, s));   // lens32 is filled batch by batch
     c->cap_reads = cap;
     return PPQC_OK;
 }
@@ -178,8 +182,7 @@ static int input_errors(const uint64_t* e) {
 }
 
 static int mark_tail(ppqc_ctx* c) {
-    HIPCHK(hipEventRecord(c->ev_tail, c->stream));
-    c->tail_recorded = true;
+    c->res_busy = true;
     return PPQC_OK;
 }
 
@@ -265,9 +268,9 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventCreate(&c->ev_s0)); HIPCHK(hipEventCreate(&c->ev_s1));
     HIPCHK(hipEventCreateWithFlags(&c->ev_max, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&c->ev_join));
     HIPCHK(hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&c->ev_reads));
     HIPCHK(hipHostMalloc((void**)&c->maxlen_host, 64, hipHostMallocDefault));
 
     // error-probability LUT: e[b] = round(2^52 * 10^(-q/10)), q = clamp(b - 33, 0, 93)
@@ -291,10 +294,11 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     // one extra word behind the results: the count of malformed device-CSR rows (never touched by init_results)
     //  [0] malformed device-CSR rows, [1] malformed FASTQ records, [2] number of the first of those,
     //  [3] invalid quality bytes seen by the GPU tokenizer (reported, not fatal)
-    HIPCHK(hipMalloc((void**)&c->res_buf, (c->res_words + 4) * 8));
+    // behind the results: 4 input-error words, then at +8 the 64 words of the sort gate (see finalize_reads_kernel)
+    HIPCHK(hipMalloc((void**)&c->res_buf, (c->res_words + 8 + kGateWords) * 8));
     HIPCHK(hipMemset(c->res_buf + c->res_words, 0, 16));
     HIPCHK(hipMemset(c->res_buf + c->res_words + 2, 0xFF, 8));
-    HIPCHK(hipMemset(c->res_buf + c->res_words + 3, 0, 8));
+    HIPCHK(hipMemset(c->res_buf + c->res_words + 3, 0, (5 + kGateWords) * 8));   // [3] bad quality bytes, [8..] sort gate
     HIPCHK(hipHostMalloc((void**)&c->res_host, (c->res_words + 4) * 8, hipHostMallocDefault));
     c->sum_buf = c->res_buf;
     c->sel_buf = c->sum_buf + tp.lay.n_sum;
@@ -325,7 +329,7 @@ int ppqc_destroy(ppqc_ctx* c) {
     if (c->ev_max) (void)hipEventDestroy(c->ev_max);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
-    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+    if (c->ev_reads) (void)hipEventDestroy(c->ev_reads);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     for (int i = 0; i < 2; ++i) {
         Slot& s = c->slot[i];
@@ -352,6 +356,7 @@ int ppqc_reset(ppqc_ctx* c) {
     c->n_reads = 0;
     c->state = 0;
     c->n50 = 0;
+    c->lens_early = true;
     return PPQC_OK;
 }
 
@@ -381,11 +386,13 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     EvPair ev{get_event(c), get_event(c), 2 * b->n_bytes + 50 * R};
     if (!ev.a || !ev.b) return fail(PPQC_E_HIP, "hipEventCreate failed");
     HIPCHK(hipEventRecord(ev.a, s));
+    c->last_a = ev.a;
     HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->n_cu, s));
     HIPCHK(hipEventRecord(ev.b, s));
     c->pending.push_back(ev);
     HIPCHK(launch_finalize_reads(v, c->ra, base, c->head, c->tail, c->tp.thr_fail, c->tp.fail_q,
-                                 c->res_buf + c->res_words, s));
+                                 c->res_buf + c->res_words, c->cfg.n_channels, c->res_buf + c->res_words + 8, s));
+    HIPCHK(hipEventRecord(c->ev_reads, s));
     c->n_reads += R;
     c->state = 0;
     return PPQC_OK;
@@ -408,9 +415,7 @@ int ppqc_submit_device(ppqc_ctx* c, const ppqc_batch* b) {
     if (((uintptr_t)b->bases & 15) || ((uintptr_t)b->quals & 15))
         return fail(PPQC_E_INVALID, "device bases/quals must be 16-byte aligned");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipEventRecord(c->ev_s0, c->stream));
     CHK(run_batch(c, b));
-    HIPCHK(hipEventRecord(c->ev_s1, c->stream));
     return PPQC_OK;
 }
 
@@ -442,7 +447,6 @@ int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
         s.cap_reads = cap;
     }
     hipStream_t cs = c->copy[si];
-    HIPCHK(hipEventRecord(c->ev_s0, c->stream));
     if (b->n_bytes) {
         HIPCHK(hipMemcpyAsync(s.bases, b->bases, b->n_bytes, hipMemcpyHostToDevice, cs));
         HIPCHK(hipMemcpyAsync(s.quals, b->quals, b->n_bytes, hipMemcpyHostToDevice, cs));
@@ -459,7 +463,6 @@ int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
     d.start_time_s = s.time; d.fail_flag = b->fail_flag ? s.ff : nullptr;
     CHK(run_batch(c, &d));
     HIPCHK(hipEventRecord(s.done, c->stream));
-    HIPCHK(hipEventRecord(c->ev_s1, c->stream));
     s.busy = true;
     return PPQC_OK;
 }
@@ -506,6 +509,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
                                  c->lut_dev, c->tp.thr_fail, c->tp.fail_q, mux, c->res_buf + c->res_words, s));
     c->n_reads += R;
     c->state = 0;
+    c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
     if (n_records) *n_records = R;
     return PPQC_OK;
 }
@@ -568,10 +572,17 @@ int ppqc_submit_records(ppqc_ctx* c, const ppqc_records* r) {
     HIPCHK(hipFree(d));
     c->n_reads += n;
     c->state = 0;
+    c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
     return PPQC_OK;
 }
 
 static int resolve_timings(ppqc_ctx* c) {
+    if (c->last_a) {   // newest batch: tile kernel + finalize_reads
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->last_a, c->ev_reads) == hipSuccess) c->timing.submit_ms_last = ms;
+        (void)hipGetLastError();
+        c->last_a = nullptr;
+    }
     for (auto& p : c->pending) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
@@ -590,6 +601,7 @@ int ppqc_sync(ppqc_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 2; ++i) c->slot[i].busy = false;
+    c->res_busy = false;
     return resolve_timings(c);
 }
 
@@ -640,14 +652,18 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     c->sum_fetched = false;
     // The result buffer is cleared on the auxiliary stream: this call is usually enqueued while the per-read kernels of
     // the batch still run, and nothing before the extremes kernel touches the results, so the clear costs no time on
-    // the main stream.  It only has to come after the last finalize phase that was enqueued before (ev_tail).
-    if (c->tail_recorded) HIPCHK(hipStreamWaitEvent(c->aux, c->ev_tail, 0));
-    HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, c->aux));
-    HIPCHK(hipEventRecord(c->ev_init, c->aux));
-    HIPCHK(hipEventRecord(c->ev_t0, s));
-    HIPCHK(hipStreamWaitEvent(s, c->ev_init, 0));
-    HIPCHK(launch_extremes(c->ra, c->n_reads, c->tp, c->max_buf, c->min_buf, c->tminmax, s));
-    HIPCHK(hipEventRecord(c->ev_max, s));   // fork point of the sort + N50 chain (ppqc_finalize_n50)
+    // the main stream.  If an earlier finalize phase may still be running (no synchronisation since), it stays in line.
+    if (!c->res_busy) {
+        HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, c->aux));
+        HIPCHK(hipEventRecord(c->ev_init, c->aux));
+        HIPCHK(hipEventRecord(c->ev_t0, s));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_init, 0));
+    } else {
+        HIPCHK(hipEventRecord(c->ev_t0, s));
+        HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, s));
+    }
+    HIPCHK(launch_extremes(c->ra, c->n_reads, c->tp, c->max_buf, c->min_buf, c->tminmax, !c->lens_early, s));
+    if (!c->lens_early) HIPCHK(hipEventRecord(c->ev_max, s));   // fork point of the sort + N50 chain (ppqc_finalize_n50)
     c->state = 1;
     return mark_tail(c);
 }
@@ -707,18 +723,24 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     hipStream_t s = c->stream;
     if (!dlens) { dlens = c->ra.lens32; n = c->n_reads; }
     if (n >= (1ull << 32)) return fail(PPQC_E_RANGE, "more than 2^32-1 lengths");
-    // The sort passes are gated on the device by max_buf[0] (the local or merged max_len bounds every key), so nothing
-    // here waits for the host.  Local lengths: the chain depends only on the extremes kernel and runs on the auxiliary
-    // stream beside the tables kernel (fork at ev_max, join before anything else is enqueued on the main stream).
-    // time_mode 1 sorts on the main stream with the same count buffer, so there the chain stays in line.
+    // The sort passes are gated on the device by a word that bounds every key (no host round trip).  Local lengths: the
+    // chain runs on the auxiliary stream beside the extremes and tables kernels.  When every read of the run came through
+    // finalize_reads, lens32 and the gate (largest key) are complete behind the last of those kernels (ev_reads);
+    // otherwise the extremes kernel writes lens32 and max_buf[0] is the gate (fork at ev_max).  Gathered lengths of
+    // other ranks are bounded by the merged max_len.  time_mode 1 sorts on the main stream with the same count buffer,
+    // so there the chain stays in line.
     const bool local = dlens == c->ra.lens32;
+    const bool early = local && c->lens_early;
     hipStream_t ss = (local && c->cfg.time_mode == 0) ? c->aux : s;
+    const uint64_t* gate = early ? c->res_buf + c->res_words + 8 : c->max_buf;
+    const int gate_words = early ? kGateWords : 1;
     CHK(ensure_sort32(c, n ? n : 1));
-    if (ss != s) HIPCHK(hipStreamWaitEvent(ss, c->ev_max, 0));
+    if (ss != s) HIPCHK(hipStreamWaitEvent(ss, early ? c->ev_reads : c->ev_max, 0));
     HIPCHK(hipEventRecord(c->ev_s0, ss));
-    HIPCHK(sort_u32_gated(dlens, c->sk32, c->sk32_tmp, n, c->counts, c->max_buf, ss));
-    HIPCHK(launch_n50_gated(dlens, c->sk32, c->sk32_tmp, c->max_buf, n, c->n50_blocks, c->n50_out, ss));
-    HIPCHK(hipEventRecord(c->ev_s1, ss));
+    HIPCHK(sort_u32_gated(dlens, c->sk32, c->sk32_tmp, n, c->counts, gate, gate_words, ss));
+    HIPCHK(launch_n50_gated(dlens, c->sk32, c->sk32_tmp, gate, gate_words, n, c->n50_blocks, c->n50_out, ss));
+    c->sort_end = c->ev_s1;
+    if (ss == s) HIPCHK(hipEventRecord(c->ev_s1, ss));
     if (ss != s) {
         if (early_fetch && c->state == 2) {
             // the SUM tables are final once the tables kernel is done: their copy to the host (1.6 MB at 512x4x48)
@@ -726,7 +748,8 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
             HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, c->tp.lay.n_sum * 8, hipMemcpyDeviceToHost, s));
             c->sum_fetched = true;
         }
-        HIPCHK(hipEventRecord(c->ev_join, ss));
+        HIPCHK(hipEventRecord(c->ev_join, ss));   // also the end of the sort timing
+        c->sort_end = c->ev_join;
         HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     }
     HIPCHK(hipEventRecord(c->ev_t1, s));
@@ -769,7 +792,7 @@ static int fetch_tables_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
     o->n50 = c->n50 = (mn + 1 + nch)[2];
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1) == hipSuccess) c->timing.finalize_ms_last = ms;
-    if (hipEventElapsedTime(&ms, c->ev_s0, c->ev_s1) == hipSuccess) c->timing.sort_ms_last = ms;
+    if (hipEventElapsedTime(&ms, c->ev_s0, c->sort_end ? c->sort_end : c->ev_s1) == hipSuccess) c->timing.sort_ms_last = ms;
     (void)hipGetLastError();   // an unrecorded event is not an error of the caller
     return PPQC_OK;
 }
@@ -823,6 +846,7 @@ int ppqc_n50_select_pick(ppqc_ctx* c, int round) {
                               kSelShift[round], kSelBits[round], round == 2, c->n50_out, c->stream));
     if (round == 2) {
         HIPCHK(hipEventRecord(c->ev_s1, c->stream));
+        c->sort_end = c->ev_s1;
         HIPCHK(hipEventRecord(c->ev_t1, c->stream));
         c->state = 3;
     }
@@ -842,9 +866,6 @@ int ppqc_set_stream(ppqc_ctx* c, void* stream, int use_external) {
 int ppqc_timings(ppqc_ctx* c, ppqc_timing* o) {
     if (!c || !o) return fail(PPQC_E_INVALID, "null argument");
     CHK(ppqc_sync(c));
-    float ms = 0.f;
-    if (c->state == 0 && hipEventElapsedTime(&ms, c->ev_s0, c->ev_s1) == hipSuccess) c->timing.submit_ms_last = ms;
-    (void)hipGetLastError();
     *o = c->timing;
     return PPQC_OK;
 }

@@ -13,6 +13,7 @@ constexpr int kSpan = kWave * kVec;     // 1 KiB: one wave-wide load of one stre
 constexpr int kMaxTileShift = 16;        // tiles are 2^shift bytes of each stream, 4 KiB .. 64 KiB (packed counters
 constexpr int kMinTileShift = 12;        // and per-lane u64 error sums are sized for <= 64 KiB)
 constexpr int kDefaultTileShift = 16;
+constexpr int kGateWords = 64;           // the sort gate is spread over 64 words (see finalize_reads_kernel)
 
 // A partial (or complete) per-read sum produced by one wave for one tile.
 //   cnt : packed counters  [0,26) sum of quality bytes, [26,44) N count, [44,62) G/C/S count
@@ -78,7 +79,7 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
                               Partial* head, Partial* tail, int n_cu, hipStream_t s, bool line_mode = false);
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint64_t thr_fail, double fail_q, uint64_t* csr_errors,
-                                 hipStream_t s);
+                                 uint32_t n_channels, uint64_t* gate, hipStream_t s);
 
 // Pre-computed reads (sequencing_summary.txt rows): device arrays of n entries appended at read_base.
 hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const uint32_t* len, const double* mean_q,
@@ -86,7 +87,7 @@ hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const u
                           double fail_q, hipStream_t s);
 
 hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* max_buf, uint64_t* min_buf,
-                           int64_t* tminmax, hipStream_t s);
+                           int64_t* tminmax, bool write_lens, hipStream_t s);
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
                          hipStream_t s);
 
@@ -110,8 +111,9 @@ uint64_t sort_count_words(uint64_t n);
 hipError_t sort_u32(const uint32_t* in, uint32_t* buf_a, uint32_t* buf_b, uint64_t n, uint32_t* counts,
                     uint32_t byte_mask, hipStream_t s, const uint32_t** out);
 // The same with all four passes enqueued and skipped on the device from gate[0] >= every key: no host round trip.
+// The bound is the OR of gate[0 .. gate_words) (1 or kGateWords).
 hipError_t sort_u32_gated(const uint32_t* in, uint32_t* buf_a, uint32_t* buf_b, uint64_t n, uint32_t* counts,
-                          const uint64_t* gate, hipStream_t s);
+                          const uint64_t* gate, int gate_words, hipStream_t s);
 hipError_t sort_u64_pairs(uint64_t* keys, uint64_t* tmp_keys, uint32_t* vals, uint32_t* tmp_vals, uint64_t n,
                           uint32_t* counts, uint32_t byte_mask, hipStream_t s);
 
@@ -120,7 +122,7 @@ uint64_t n50_block_words(uint64_t n);
 hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s);
 // after sort_u32_gated(in, buf_a, buf_b, .., gate): picks the buffer the sorted keys ended in from the same gate word
 hipError_t launch_n50_gated(const uint32_t* in, const uint32_t* buf_a, const uint32_t* buf_b, const uint64_t* gate,
-                            uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s);
+                            int gate_words, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s);
 
 // Exact N50 by MSD radix select (multi-GPU path).  state = {prefix, weight of all longer keys}; sel = PPQC_N_SEL u64.
 // hist: sel[d] += sum of the lengths whose bits above `shift + nbits` equal the prefix and whose digit is d.
@@ -199,6 +201,14 @@ __device__ __forceinline__ SegSums merged_sums(uint64_t a, uint64_t e, uint64_t 
         }
     }
     return r;
+}
+// OR of the gate words, for kernels whose blocks are whole waves: lane l reads word l, six xor-shuffle steps.
+__device__ __forceinline__ uint64_t gate_bound(const uint64_t* __restrict__ gate, int words) {
+    const int lane = threadIdx.x & 63;
+    uint64_t v = gate[lane < words ? lane : 0];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v |= __shfl_xor(v, o);
+    return v;
 }
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
     uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);

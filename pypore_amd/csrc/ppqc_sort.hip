@@ -35,9 +35,9 @@ uint64_t sort_count_words(uint64_t n) {
 template <typename K>
 __global__ __launch_bounds__(256) void rs_hist_kernel(const K* __restrict__ keys, uint64_t n, int shift,
                                                       uint32_t* __restrict__ counts, uint32_t NW, uint32_t chunk,
-                                                      const uint64_t* __restrict__ gate) {
+                                                      const uint64_t* __restrict__ gate, int gate_words) {
     __shared__ uint32_t h[4][256];
-    if (gate && shift && (gate[0] >> shift) == 0) return;   // device-gated pass: no key has a bit at or above `shift`
+    if (gate && shift && (gate_bound(gate, gate_words) >> shift) == 0) return;   // device-gated pass: no key has a bit at or above `shift`
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const uint32_t w = blockIdx.x * 4 + wib;
     for (int d = lane; d < 256; d += 64) h[wib][d] = 0;
@@ -66,9 +66,9 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const K* __restrict__ keys
 
 // Block d: exclusive scan of row d (NW entries) in place; row total -> counts[256*NW + d].
 __global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ counts, uint32_t NW, int shift,
-                                                      const uint64_t* __restrict__ gate) {
+                                                      const uint64_t* __restrict__ gate, int gate_words) {
     __shared__ uint32_t part[256];
-    if (gate && shift && (gate[0] >> shift) == 0) return;
+    if (gate && shift && (gate_bound(gate, gate_words) >> shift) == 0) return;
     const uint32_t d = blockIdx.x, t = threadIdx.x;
     uint32_t* row = counts + (uint64_t)d * NW;
     const uint32_t seg = (NW + 255) / 256;
@@ -92,9 +92,9 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const K* __restrict__ k
                                                          K* __restrict__ okeys, uint32_t* __restrict__ ovals,
                                                          uint64_t n, int shift, const uint32_t* __restrict__ counts,
                                                          uint32_t NW, uint32_t chunk,
-                                                         const uint64_t* __restrict__ gate) {
+                                                         const uint64_t* __restrict__ gate, int gate_words) {
     __shared__ uint32_t base[4][256];
-    if (gate && shift && (gate[0] >> shift) == 0) return;
+    if (gate && shift && (gate_bound(gate, gate_words) >> shift) == 0) return;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const uint32_t w = blockIdx.x * 4 + wib;
     if (w >= NW) return;   // whole waves leave; no block-level barrier below
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const K* __restrict__ k
 template <typename K, bool HAS_VAL>
 static hipError_t radix_sort(const K* in, K* buf_a, K* buf_b, const uint32_t* vin, uint32_t* va, uint32_t* vb,
                              uint64_t n, uint32_t* counts, uint32_t byte_mask, hipStream_t s, const K** out,
-                             const uint32_t** vout, const uint64_t* gate = nullptr) {
+                             const uint32_t** vout, const uint64_t* gate = nullptr, int gate_words = 1) {
     *out = in;
     if (vout) *vout = vin;
     if (n < 2) return hipSuccess;
@@ -171,10 +171,10 @@ static hipError_t radix_sort(const K* in, K* buf_a, K* buf_b, const uint32_t* vi
     for (int byte = 0; byte < (int)sizeof(K); ++byte) {
         if (!((byte_mask >> byte) & 1u)) continue;
         const int shift = 8 * byte;
-        hipLaunchKernelGGL((rs_hist_kernel<K>), dim3(blocks), dim3(256), 0, s, src, n, shift, counts, NW, chunk, gate);
-        hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, s, counts, NW, shift, gate);
+        hipLaunchKernelGGL((rs_hist_kernel<K>), dim3(blocks), dim3(256), 0, s, src, n, shift, counts, NW, chunk, gate, gate_words);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, s, counts, NW, shift, gate, gate_words);
         hipLaunchKernelGGL((rs_scatter_kernel<K, HAS_VAL>), dim3(blocks), dim3(256), 0, s, src, vsrc, dst, vdst, n,
-                           shift, counts, NW, chunk, gate);
+                           shift, counts, NW, chunk, gate, gate_words);
         src = dst; vsrc = vdst;
         dst = dst == buf_a ? buf_b : buf_a;
         vdst = vdst == va ? vb : va;
@@ -194,10 +194,10 @@ hipError_t sort_u32(const uint32_t* in, uint32_t* buf_a, uint32_t* buf_b, uint64
 // The passes that run are 0..top, so the buffer roles are static (in -> a -> b -> a -> b) and the sorted keys end in
 // buf_a when top is even, else buf_b: launch_n50_gated makes the same choice from the same word.  No host round trip.
 hipError_t sort_u32_gated(const uint32_t* in, uint32_t* buf_a, uint32_t* buf_b, uint64_t n, uint32_t* counts,
-                          const uint64_t* gate, hipStream_t s) {
+                          const uint64_t* gate, int gate_words, hipStream_t s) {
     const uint32_t* out = nullptr;
     return radix_sort<uint32_t, false>(in, buf_a, buf_b, nullptr, nullptr, nullptr, n, counts, 0xFu, s, &out, nullptr,
-                                       gate);
+                                       gate, gate_words);
 }
 hipError_t sort_u64_pairs(uint64_t* keys, uint64_t* tmp_keys, uint32_t* vals, uint32_t* tmp_vals, uint64_t n,
                           uint32_t* counts, uint32_t byte_mask, hipStream_t s) {
@@ -223,20 +223,20 @@ uint64_t n50_block_words(uint64_t n) { return (n + kN50Block - 1) / kN50Block + 
 
 // Which buffer holds the sorted keys after a gated sort (see sort_u32_gated); without a gate it is `a`.
 __device__ __forceinline__ const uint32_t* gated_pick(const uint32_t* a, const uint32_t* b, const uint64_t* gate,
-                                                      const uint32_t* in, uint64_t n) {
+                                                      int gate_words, const uint32_t* in, uint64_t n) {
     if (!gate) return a;
     if (n < 2) return in;   // radix_sort enqueues nothing for fewer than two keys
-    const uint64_t m = gate[0];
+    const uint64_t m = gate_bound(gate, gate_words);
     const int top = m < (1ull << 8) ? 0 : (m < (1ull << 16) ? 1 : (m < (1ull << 24) ? 2 : 3));
     return (top & 1) ? b : a;
 }
 
 __global__ __launch_bounds__(256) void n50_blocksum_kernel(const uint32_t* __restrict__ sa,
                                                            const uint32_t* __restrict__ sb,
-                                                           const uint64_t* __restrict__ gate,
+                                                           const uint64_t* __restrict__ gate, int gate_words,
                                                            const uint32_t* __restrict__ in, uint64_t n,
                                                            uint64_t* __restrict__ bsum) {
-    const uint32_t* __restrict__ s = gated_pick(sa, sb, gate, in, n);
+    const uint32_t* __restrict__ s = gated_pick(sa, sb, gate, gate_words, in, n);
     __shared__ unsigned long long acc;
     if (threadIdx.x == 0) acc = 0;
     __syncthreads();
@@ -276,10 +276,10 @@ __global__ __launch_bounds__(256) void n50_scan_kernel(uint64_t* __restrict__ bs
 
 __global__ __launch_bounds__(256) void n50_find_kernel(const uint32_t* __restrict__ sa,
                                                        const uint32_t* __restrict__ sb,
-                                                       const uint64_t* __restrict__ gate,
+                                                       const uint64_t* __restrict__ gate, int gate_words,
                                                        const uint32_t* __restrict__ in, uint64_t n,
                                                        const uint64_t* __restrict__ bsuf, uint64_t* __restrict__ out) {
-    const uint32_t* __restrict__ s = gated_pick(sa, sb, gate, in, n);
+    const uint32_t* __restrict__ s = gated_pick(sa, sb, gate, gate_words, in, n);
     __shared__ uint64_t part[256];
     const uint64_t total = out[1];
     if (total == 0) return;
@@ -307,21 +307,21 @@ __global__ __launch_bounds__(256) void n50_find_kernel(const uint32_t* __restric
     }
 }
 
-static hipError_t n50_launch(const uint32_t* sa, const uint32_t* sb, const uint64_t* gate, const uint32_t* in,
-                             uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
+static hipError_t n50_launch(const uint32_t* sa, const uint32_t* sb, const uint64_t* gate, int gate_words,
+                             const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
     if (n == 0) return hipMemsetAsync(out, 0, 16, s);
     const uint64_t nblocks = (n + kN50Block - 1) / kN50Block;
-    hipLaunchKernelGGL(n50_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sa, sb, gate, in, n, block_sums);
+    hipLaunchKernelGGL(n50_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sa, sb, gate, gate_words, in, n, block_sums);
     hipLaunchKernelGGL(n50_scan_kernel, dim3(1), dim3(256), 0, s, block_sums, nblocks, out);
-    hipLaunchKernelGGL(n50_find_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sa, sb, gate, in, n, block_sums, out);
+    hipLaunchKernelGGL(n50_find_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sa, sb, gate, gate_words, in, n, block_sums, out);
     return hipGetLastError();
 }
 hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
-    return n50_launch(sorted, nullptr, nullptr, sorted, n, block_sums, out, s);
+    return n50_launch(sorted, nullptr, nullptr, 1, sorted, n, block_sums, out, s);
 }
 hipError_t launch_n50_gated(const uint32_t* in, const uint32_t* buf_a, const uint32_t* buf_b, const uint64_t* gate,
-                            uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
-    return n50_launch(buf_a, buf_b, gate, in, n, block_sums, out, s);
+                            int gate_words, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
+    return n50_launch(buf_a, buf_b, gate, gate_words, in, n, block_sums, out, s);
 }
 
 // ---- N50 by weighted radix select (multi-GPU: only PPQC_N_SEL-word histograms cross xGMI) --------------------------

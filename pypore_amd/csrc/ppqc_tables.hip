@@ -24,7 +24,7 @@ __device__ __forceinline__ int32_t hour_of_day(int64_t t, const TableParams& tp)
 // Per-channel min/max are privatised in LDS (u32 pairs, dynamic: 8 B per channel) when they fit, and flushed once per
 // block; run extremes go through thread-local registers, one LDS atomic per thread, one global atomic per block.
 __global__ __launch_bounds__(1024) void extremes_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* max_buf,
-                                                       uint64_t* min_buf, int64_t* tminmax, uint32_t nchL) {
+                                                       uint64_t* min_buf, int64_t* tminmax, uint32_t nchL, int write_lens) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* s_cmax = reinterpret_cast<uint32_t*>(smem);
     uint32_t* s_cmin = s_cmax + nchL;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(1024) void extremes_kernel(ReadArrays ra, uint64_t 
         const uint32_t ch = ra.channel[i];
         const bool good = ch >= 1 && ch <= nch;
         const uint32_t L = ra.len[i];
-        ra.lens32[i] = good ? L : 0;
+        if (write_lens) ra.lens32[i] = good ? L : 0;   // else finalize_reads left it (and a sort may be reading it)
         int32_t hour = -1;
         if (good) {
             lmax = L > lmax ? L : lmax;
@@ -272,12 +272,12 @@ hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const u
 }
 
 // the four input-error words behind the results: [0] bad CSR rows, [1] bad FASTQ records, [2] first of them, [3] bad
-// quality bytes
+// quality bytes; [8 .. 8 + kGateWords) the sort gate (OR of the sort keys of the run, raised by finalize_reads)
 __global__ void reset_errors_kernel(uint64_t* e) {
-    if (threadIdx.x < 4) e[threadIdx.x] = threadIdx.x == 2 ? ~0ull : 0ull;
+    if (threadIdx.x < 8 + kGateWords) e[threadIdx.x] = threadIdx.x == 2 ? ~0ull : 0ull;
 }
 hipError_t launch_reset_errors(uint64_t* e, hipStream_t s) {
-    hipLaunchKernelGGL(reset_errors_kernel, dim3(1), dim3(64), 0, s, e);
+    hipLaunchKernelGGL(reset_errors_kernel, dim3(1), dim3(128), 0, s, e);
     return hipGetLastError();
 }
 
@@ -312,13 +312,13 @@ static inline unsigned grid_for(uint64_t n, unsigned cap) {
 }
 
 hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* max_buf, uint64_t* min_buf,
-                           int64_t* tminmax, hipStream_t s) {
+                           int64_t* tminmax, bool write_lens, hipStream_t s) {
     if (n == 0) return hipSuccess;
     // a length of 2^32-1 cannot be told from "unseen" in the u32 LDS copy: lengths are < 2^32-1 by the API contract
     const uint32_t nchL = tp.lay.n_channels <= 8192 ? tp.lay.n_channels : 0;
     hipLaunchKernelGGL(extremes_kernel, dim3(grid_for(n, env_or("PPQC_EXT_BLOCKS", 256))),
                        dim3(env_or("PPQC_EXT_THREADS", 512)), (size_t)nchL * 8, s, ra, n, tp, max_buf, min_buf, tminmax,
-                       nchL);
+                       nchL, write_lens ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -533,53 +533,70 @@ void tile_kernel_line(BatchView b, const uint64_t* __restrict__ lut_g, ReadArray
 }
 
 // One thread per read: merge the partials of reads that span tiles, define empty reads, then decode the raw sums.
+// Also leaves the sort input of the run (lens32: the length, 0 for reads without a valid channel) and raises `gate`, the
+// device words whose OR bounds every sort key, so that the sort + N50 chain can start right behind this kernel.
 __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadArrays ra, uint64_t read_base,
                                                              const Partial* __restrict__ head,
                                                              const Partial* __restrict__ tail, uint64_t thr_fail,
-                                                             double fail_q, uint64_t* __restrict__ csr_errors) {
+                                                             double fail_q, uint64_t* __restrict__ csr_errors,
+                                                             uint32_t n_channels, uint64_t* __restrict__ gate) {
+    __shared__ uint32_t s_max;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.n_reads) return;
-    uint64_t a = b.offsets[i], e = b.offsets[i + 1];
-    // A device batch cannot be validated on the host: a malformed CSR must neither fault (the partial arrays are
-    // indexed by tile) nor pass silently -- the read is zeroed and counted; ppqc_fetch_tables / ppqc_read_stats fail.
-    if (e < a || e > b.n_bytes || e - a >= 0xFFFFFFFFull || (i == 0 && a != 0) || (i + 1 == b.n_reads && e != b.n_bytes)) {
-        atomicAdd((unsigned long long*)csr_errors, 1ull);
-        a = e = 0;
-    }
-    const uint64_t L = e - a, g = read_base + i;
-    uint64_t gcs = 0, nn = 0, qb = 0, hi = 0, lo = 0;
-    if (L != 0) {
-        const SegSums m = merged_sums(a, e, g, ra, head, tail, b.tile_shift);
-        gcs = m.gcs; nn = m.nn; qb = m.qb; hi = m.hi; lo = m.lo;
-    }
-    // canonical split S = H * 2^32 + l32, then one correctly rounded conversion to fp64
-    const uint64_t H = hi + (lo >> 32), l32 = lo & 0xffffffffull;
-    const bool flagged = b.fail_flag != nullptr && b.fail_flag[i] != 0;
-    uint8_t flags = 0;
-    double mq = 0.0;
-    if (flagged) {
-        // lib/fast5_reader.py:37-40: a 'fail' path keeps ReadLength = 0, QScore = 6.99, GCcont = 0
-        flags = 2 | (6.99 < fail_q ? 1 : 0);
-        ra.len[g] = 0; ra.gc[g] = 0; ra.nn[g] = 0; ra.qsum[g] = 0; ra.err_hi[g] = 0; ra.err_lo[g] = 0;
-        mq = 6.99;
-    } else {
-        if (L != 0) {
-            const double S = (double)H * 4294967296.0 + (double)l32;
-            mq = -10.0 * log10(S / ((double)L * 4503599627370496.0));
-            const unsigned __int128 S128 = ((unsigned __int128)H << 32) + l32;
-            flags = S128 > (unsigned __int128)L * thr_fail ? 1 : 0;
-        } else {
-            flags = 0.0 < fail_q ? 1 : 0;
+    if (i < b.n_reads) {
+        uint64_t a = b.offsets[i], e = b.offsets[i + 1];
+        // A device batch cannot be validated on the host: a malformed CSR must neither fault (the partial arrays are
+        // indexed by tile) nor pass silently -- the read is zeroed and counted; ppqc_fetch_tables / ppqc_read_stats fail.
+        if (e < a || e > b.n_bytes || e - a >= 0xFFFFFFFFull || (i == 0 && a != 0) ||
+            (i + 1 == b.n_reads && e != b.n_bytes)) {
+            atomicAdd((unsigned long long*)csr_errors, 1ull);
+            a = e = 0;
         }
-        ra.len[g] = (uint32_t)L; ra.gc[g] = (uint32_t)gcs; ra.nn[g] = (uint32_t)nn;
-        ra.qsum[g] = (int64_t)qb - 33 * (int64_t)L;
-        ra.err_hi[g] = H; ra.err_lo[g] = l32;
+        const uint64_t L = e - a, g = read_base + i;
+        uint64_t gcs = 0, nn = 0, qb = 0, hi = 0, lo = 0;
+        if (L != 0) {
+            const SegSums m = merged_sums(a, e, g, ra, head, tail, b.tile_shift);
+            gcs = m.gcs; nn = m.nn; qb = m.qb; hi = m.hi; lo = m.lo;
+        }
+        // canonical split S = H * 2^32 + l32, then one correctly rounded conversion to fp64
+        const uint64_t H = hi + (lo >> 32), l32 = lo & 0xffffffffull;
+        const bool flagged = b.fail_flag != nullptr && b.fail_flag[i] != 0;
+        uint8_t flags = 0;
+        double mq = 0.0;
+        uint32_t len_out = 0;
+        if (flagged) {
+            // lib/fast5_reader.py:37-40: a 'fail' path keeps ReadLength = 0, QScore = 6.99, GCcont = 0
+            flags = 2 | (6.99 < fail_q ? 1 : 0);
+            ra.len[g] = 0; ra.gc[g] = 0; ra.nn[g] = 0; ra.qsum[g] = 0; ra.err_hi[g] = 0; ra.err_lo[g] = 0;
+            mq = 6.99;
+        } else {
+            if (L != 0) {
+                const double S = (double)H * 4294967296.0 + (double)l32;
+                mq = -10.0 * log10(S / ((double)L * 4503599627370496.0));
+                const unsigned __int128 S128 = ((unsigned __int128)H << 32) + l32;
+                flags = S128 > (unsigned __int128)L * thr_fail ? 1 : 0;
+            } else {
+                flags = 0.0 < fail_q ? 1 : 0;
+            }
+            len_out = (uint32_t)L;
+            ra.len[g] = (uint32_t)L; ra.gc[g] = (uint32_t)gcs; ra.nn[g] = (uint32_t)nn;
+            ra.qsum[g] = (int64_t)qb - 33 * (int64_t)L;
+            ra.err_hi[g] = H; ra.err_lo[g] = l32;
+        }
+        const uint32_t ch = b.channel[i];
+        const uint32_t key = (ch >= 1 && ch <= n_channels) ? len_out : 0u;   // what extremes_kernel would write
+        ra.lens32[g] = key;
+        if (key) atomicMax(&s_max, key);
+        ra.mean_q[g] = mq;
+        ra.flags[g] = flags;
+        ra.channel[g] = ch;
+        ra.mux[g] = b.mux[i];
+        ra.time[g] = b.time[i];
     }
-    ra.mean_q[g] = mq;
-    ra.flags[g] = flags;
-    ra.channel[g] = b.channel[i];
-    ra.mux[g] = b.mux[i];
-    ra.time[g] = b.time[i];
+    __syncthreads();
+    // 64 gate words, picked by block: thousands of atomics on ONE address would serialise (measured: +40 us)
+    if (threadIdx.x == 0 && s_max) atomicOr((unsigned long long*)&gate[blockIdx.x & (kGateWords - 1)], (unsigned long long)s_max);
 }
 
 constexpr uint64_t kVecbMeanLen = 448;   // mean read length (bytes) below which the VECB kernel is launched
@@ -632,11 +649,11 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
 
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint64_t thr_fail, double fail_q, uint64_t* csr_errors,
-                                 hipStream_t s) {
+                                 uint32_t n_channels, uint64_t* gate, hipStream_t s) {
     if (b.n_reads == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((b.n_reads + 255) / 256);
     hipLaunchKernelGGL(finalize_reads_kernel, dim3(blocks), dim3(256), 0, s, b, ra, read_base, head, tail, thr_fail,
-                       fail_q, csr_errors);
+                       fail_q, csr_errors, n_channels, gate);
     return hipGetLastError();
 }
 
