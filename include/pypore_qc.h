@@ -152,11 +152,13 @@ typedef struct ppqc_tables {
 } ppqc_tables;
 
 /* Device-side view of the mergeable tables, for RCCL all-reduce through torch.distributed:
- * sum_buf (n_sum u64, SUM), max_buf (n_max u64, MAX), min_buf (n_min u64, MIN; empty = INT64_MAX). */
+ * sum_buf (n_sum u64, SUM), max_buf (n_max i64, MAX), min_buf (n_min i64, holds the bitwise COMPLEMENT of each minimum,
+ * ~INT64_MAX if empty, so it also merges by MAX): min_buf == max_buf + n_max, one all-reduce(MAX) of n_max + n_min words
+ * merges both.  ppqc_fetch_tables decodes the minima. */
 typedef struct ppqc_device_tables {
     void* sum_buf; uint64_t n_sum;
     void* max_buf; uint64_t n_max;   /* [0] = max_len, [1..] = chan_max_len */
-    void* min_buf; uint64_t n_min;   /* [0] = min_pos_len, [1..] = chan_min_len */
+    void* min_buf; uint64_t n_min;   /* [0] = ~min_pos_len, [1..] = ~chan_min_len */
     void* lengths; uint64_t n_lengths; /* uint32 per read (0 for bad-channel / flagged reads): N50 input */
     /* offsets (in u64 elements) of each table inside sum_buf */
     uint64_t off_totals, off_len_log2, off_len_lin, off_q_hist, off_gc_hist, off_hour_reads, off_hour_bases,
@@ -226,7 +228,7 @@ int ppqc_read_hours(ppqc_ctx* ctx, int32_t* out, uint64_t first, uint64_t n);
 
 /* Run-level aggregation (replaces parsing_func's aggregation + the sums of FastStats), in phases so a
  * multi-GPU caller can all-reduce between them:
- *   ppqc_finalize_extremes -> [all-reduce MAX max_buf, MIN min_buf]
+ *   ppqc_finalize_extremes -> [all-reduce MAX of max_buf | min_buf (one call)]
  *   ppqc_finalize_tables   -> [all-reduce SUM sum_buf]
  *   ppqc_finalize_n50(ctx, NULL, 0) or, multi-GPU, with the all-gathered device array of lengths
  *   ppqc_fetch_tables

@@ -56,6 +56,7 @@ struct ppqc_ctx {
     hipStream_t stream = nullptr, own_stream = nullptr, copy[2] = {nullptr, nullptr};
     hipStream_t aux = nullptr;      // the sort + N50 chain runs here, beside the tables kernel on `stream`
     hipEvent_t ev_join = nullptr, ev_init = nullptr;
+    bool init_on_aux = false;   // the last clear of the result buffer went to the auxiliary stream
     bool res_busy = false;   // a finalize phase (or a caller's collective on the tables) may still run: set by every
                              // finalize phase, cleared when the stream has been synchronised
     hipEvent_t last_a = nullptr, sort_end = nullptr;   // start event of the newest batch (submit_ms_last)
@@ -653,6 +654,7 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     // The result buffer is cleared on the auxiliary stream: this call is usually enqueued while the per-read kernels of
     // the batch still run, and nothing before the extremes kernel touches the results, so the clear costs no time on
     // the main stream.  If an earlier finalize phase may still be running (no synchronisation since), it stays in line.
+    c->init_on_aux = !c->res_busy;
     if (!c->res_busy) {
         HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, c->aux));
         HIPCHK(hipEventRecord(c->ev_init, c->aux));
@@ -770,6 +772,10 @@ static int fetch_tables_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
                           c->stream));
     c->sum_fetched = false;
     CHK(ppqc_sync(c));
+    {   // the device keeps the minima complemented (one all-reduce MAX merges maxima and minima): decode in place
+        uint64_t* mnw = c->res_host + c->tp.lay.n_sum + PPQC_N_SEL + 1 + (uint64_t)c->tp.lay.n_channels;
+        for (uint64_t k = 0; k < 1 + (uint64_t)c->tp.lay.n_channels; ++k) mnw[k] = ~mnw[k];
+    }
     const uint64_t* h = c->res_host;
     CHK(input_errors(h + c->res_words));
     const uint64_t nch = l.n_channels, nb = l.n_time_bins, cells = nch * l.n_mux * nb;
@@ -831,9 +837,17 @@ int ppqc_n50_select_hist(ppqc_ctx* c, int round) {
     if (round < 0 || round > 2) return fail(PPQC_E_INVALID, "round must be 0, 1 or 2");
     if (c->state < 1) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes first");
     HIPCHK(hipSetDevice(c->device));
-    if (round == 0) HIPCHK(hipEventRecord(c->ev_s0, c->stream));
-    HIPCHK(launch_select_hist(c->ra.lens32, c->n_reads, kSelShift[round], kSelBits[round], c->sel_state, c->sel_buf,
-                              c->stream));
+    // Round 0 needs only the lengths: when finalize_reads left them (lens_early) it runs on the auxiliary stream, beside
+    // the extremes kernel, the caller's extremes all-reduce and the tables kernel, and joins the main stream here.
+    const bool side = round == 0 && c->lens_early && c->init_on_aux;   // the clear of sel_buf must precede on aux
+    hipStream_t ss = side ? c->aux : c->stream;
+    if (side) HIPCHK(hipStreamWaitEvent(ss, c->ev_reads, 0));
+    if (round == 0) HIPCHK(hipEventRecord(c->ev_s0, ss));
+    HIPCHK(launch_select_hist(c->ra.lens32, c->n_reads, kSelShift[round], kSelBits[round], c->sel_state, c->sel_buf, ss));
+    if (side) {
+        HIPCHK(hipEventRecord(c->ev_join, ss));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    }
     return mark_tail(c);
 }
 

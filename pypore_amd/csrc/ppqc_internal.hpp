@@ -92,7 +92,7 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
                          hipStream_t s);
 
 hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s);
-// res = [n_zero sums (tables + select histogram) = 0 | nch1 max = 0 | nch1 min = INT64_MAX | tmin = INT64_MAX,
+// res = [n_zero sums (tables + select histogram) = 0 | nch1 max = 0 | nch1 ~min = ~INT64_MAX | tmin = INT64_MAX,
 //        tmax = INT64_MIN | n50, total = 0 | 4 words of select state = 0]
 hipError_t launch_init_results(uint64_t* res, uint64_t n_zero, uint64_t nch1, hipStream_t s);
 hipError_t launch_reset_errors(uint64_t* e, hipStream_t s);

@@ -23,6 +23,8 @@ __device__ __forceinline__ int32_t hour_of_day(int64_t t, const TableParams& tp)
 // ---- pass 1: extremes, sort input, absolute hour bins --------------------------------------------------------------
 // Per-channel min/max are privatised in LDS (u32 pairs, dynamic: 8 B per channel) when they fit, and flushed once per
 // block; run extremes go through thread-local registers, one LDS atomic per thread, one global atomic per block.
+// min_buf holds the bitwise complement of each minimum (signed: ~L = -L-1, unseen = ~INT64_MAX = INT64_MIN), so that a
+// minimum is merged by MAX and [max_buf | min_buf] crosses xGMI in ONE all-reduce(MAX).
 __global__ __launch_bounds__(1024) void extremes_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* max_buf,
                                                        uint64_t* min_buf, int64_t* tminmax, uint32_t nchL, int write_lens) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(1024) void extremes_kernel(ReadArrays ra, uint64_t 
                 atomicMin(&s_cmin[ch - 1], L);
             } else {
                 atomicMax((unsigned long long*)&max_buf[ch], (unsigned long long)L);
-                atomicMin((unsigned long long*)&min_buf[ch], (unsigned long long)L);
+                atomicMax((long long*)&min_buf[ch], ~(long long)L);
             }
             const int64_t t = ra.time[i];
             tmin = t < tmin ? t : tmin;
@@ -69,12 +71,12 @@ __global__ __launch_bounds__(1024) void extremes_kernel(ReadArrays ra, uint64_t 
     for (uint32_t k = threadIdx.x; k < nchL; k += blockDim.x) {
         if (s_cmin[k] != 0xFFFFFFFFu) {   // channel seen by this block
             atomicMax((unsigned long long*)&max_buf[1 + k], (unsigned long long)s_cmax[k]);
-            atomicMin((unsigned long long*)&min_buf[1 + k], (unsigned long long)s_cmin[k]);
+            atomicMax((long long*)&min_buf[1 + k], ~(long long)s_cmin[k]);
         }
     }
     if (threadIdx.x == 0) {
         atomicMax((unsigned long long*)&max_buf[0], s_max);
-        atomicMin((unsigned long long*)&min_buf[0], s_min);
+        atomicMax((long long*)&min_buf[0], ~(long long)s_min);
         atomicMin((long long*)&tminmax[0], s_tmin);
         atomicMax((long long*)&tminmax[1], s_tmax);
     }
@@ -285,7 +287,7 @@ __global__ void init_results_kernel(uint64_t* res, uint64_t n_sum, uint64_t nch1
     const uint64_t total = n_sum + 2 * nch1 + 8;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t v = 0;
-        if (i >= n_sum + nch1 && i < n_sum + 2 * nch1) v = (uint64_t)INT64_MAX;          // min section
+        if (i >= n_sum + nch1 && i < n_sum + 2 * nch1) v = (uint64_t)INT64_MIN;          // min section: ~INT64_MAX
         else if (i == n_sum + 2 * nch1) v = (uint64_t)INT64_MAX;                         // tmin
         else if (i == n_sum + 2 * nch1 + 1) v = (uint64_t)INT64_MIN;                     // tmax
         res[i] = v;

@@ -6,7 +6,8 @@ collective; only the small integer tables are merged -- the counterpart of gathe
 the multiprocessing result queue in the reference (lib/seq_routines.py:940-942) and of the sum over channels in
 FastStats (lib/seq_routines.py:103-108):
 
-  1. all-reduce MAX on [max_len | chan_max_len], MIN on [min_pos_len | chan_min_len]   (a few KB)
+  1. one all-reduce MAX on [max_len | chan_max_len | ~min_pos_len | ~chan_min_len] (a few KB; the device keeps the
+     minima bitwise complemented so that they merge by MAX too)
   2. all-reduce SUM on the fused u64 table buffer (1.6 MB at 512x4x48, 13.9 MB at 3000x4x72) -- one call; at these
      sizes the ring is latency-bound on xGMI, so it is not bucketed or pipelined
   3. exact N50 by weighted radix select: three 2048-word histograms all-reduced (the first fused into step 2); the
@@ -53,10 +54,9 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True):
         ctx.set_stream(handle)
     ctx.finalize_extremes()
     views, _ = ctx.device_tables()
-    t_max = torch.as_tensor(views["max"], device="cuda")
-    t_min = torch.as_tensor(views["min"], device="cuda")
-    dist.all_reduce(t_max, op=dist.ReduceOp.MAX, group=group)
-    dist.all_reduce(t_min, op=dist.ReduceOp.MIN, group=group)
+    # the device keeps the minima complemented, so maxima and minima merge in ONE all-reduce(MAX)
+    t_maxmin = torch.as_tensor(views["maxmin"], device="cuda")
+    dist.all_reduce(t_maxmin, op=dist.ReduceOp.MAX, group=group)
     ctx.finalize_tables()                        # length histogram bins use the merged max_len
     if n50 == "select":
         t_sum_sel = torch.as_tensor(views["sum_sel"], device="cuda")

@@ -273,12 +273,14 @@ class QCContext:
         return self._tables_dict(arr, t)
 
     def device_tables(self):
-        """Zero-copy device views {sum, max, min (int64), lengths (uint32)} plus the table offsets."""
+        """Zero-copy device views {sum, max, min, maxmin (int64), lengths (uint32)} plus the table offsets.
+        ``min`` holds the bitwise complement of the minima, so ``maxmin`` = [max | ~min] merges with one MAX."""
         d = L.DeviceTables()
         L.check(self._lib.ppqc_device_tables_view(self._ctx, C.byref(d)))
         views = dict(sum=DeviceArrayView(d.sum_buf, d.n_sum, "<i8", self),
                      max=DeviceArrayView(d.max_buf, d.n_max, "<i8", self),
-                     min=DeviceArrayView(d.min_buf, d.n_min, "<i8", self),
+                     min=DeviceArrayView(d.min_buf, d.n_min, "<i8", self),          # complemented minima (merge by MAX)
+                     maxmin=DeviceArrayView(d.max_buf, d.n_max + d.n_min, "<i8", self),
                      lengths=DeviceArrayView(d.lengths, d.n_lengths, "<i4", self),
                      sel=DeviceArrayView(d.sel_buf, d.n_sel, "<i8", self),
                      sum_sel=DeviceArrayView(d.sum_buf, d.n_sum + d.n_sel, "<i8", self))

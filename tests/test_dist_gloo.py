@@ -44,7 +44,11 @@ def _worker(rank, world, port, tmp):
         keys = ("totals", "len_hist_log2", "q_hist", "gc_hist", "hour_reads", "hour_bases", "chan_reads", "chan_bases",
                 "chan_fail", "cmh_reads", "cmh_bases")
         t_sum = torch.from_numpy(np.concatenate([np.asarray(loc[k]).reshape(-1) for k in keys]).astype(np.int64))
+        # the device layout [max | ~min] merges in ONE all-reduce(MAX) (finalize_distributed); same result as MAX + MIN
+        t_maxmin = torch.cat([t_max, ~t_min])
+        dist.all_reduce(t_maxmin, op=dist.ReduceOp.MAX)
         merge.allreduce_table_tensors(t_sum, t_max, t_min, dist)
+        assert torch.equal(t_maxmin[: t_max.numel()], t_max) and torch.equal(~t_maxmin[t_max.numel():], t_min)
         lens = np.where((meta[0] >= 1) & (meta[0] <= 24) & (meta[3] == 0), st["length"], 0).astype(np.int32)
         all_lens = merge.gather_lengths(torch.from_numpy(lens), dist, torch)
         # reference: one shard over the concatenation
