@@ -68,7 +68,10 @@ __device__ __forceinline__ uint32_t odd_byte_mask(uint32_t x) {
 __device__ __forceinline__ uint4 load_vec_clamped(const uint8_t* __restrict__ text, uint64_t pos, uint64_t n) {
     // 16-byte aligned load; a vector that starts beyond the data is replaced by the last in-bounds one (masked later)
     const uint64_t last = (n - 1) & ~15ull;
-    return *reinterpret_cast<const uint4*>(text + (pos < last ? pos : last));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // each pass streams the text once: nontemporal, like the tile kernel's loads
+    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(text + (pos < last ? pos : last)));
+    return make_uint4(t[0], t[1], t[2], t[3]);
 }
 
 // one wave per chunk of kNlChunk bytes

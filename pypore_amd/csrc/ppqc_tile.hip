@@ -525,11 +525,11 @@ __global__ __launch_bounds__(256, (VECB ? 3 : 4)) void tile_kernel(BatchView b, 
 
 // Line mode (FASTQ text): one stream.  8 spans per batch at 5 waves per SIMD (95 VGPRs); 16 spans spill (measured
 // 1.0 TB/s of text against 1.27 TB/s for the whole tokenizer path).
-template <int NB>
+template <int NB, bool VECB>
 __global__ __launch_bounds__(256)
 void tile_kernel_line(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra, uint64_t read_base,
                       Partial* __restrict__ head, Partial* __restrict__ tail, uint64_t n_tiles) {
-    tile_body<NB, true, false, true, true>(b, lut_g, ra, read_base, head, tail, n_tiles);
+    tile_body<NB, true, false, true, VECB>(b, lut_g, ra, read_base, head, tail, n_tiles);
 }
 
 // One thread per read: merge the partials of reads that span tiles, define empty reads, then decode the raw sums.
@@ -615,7 +615,7 @@ static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_de
     }
     if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
     if (LINE)
-        hipLaunchKernelGGL((tile_kernel_line<NB>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base,
+        hipLaunchKernelGGL((tile_kernel_line<NB, VECB>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base,
                            head, tail, n_tiles);
     else
         hipLaunchKernelGGL((tile_kernel<NB, NT, PIPE, VECB>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra,
@@ -627,7 +627,14 @@ static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_de
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
                               Partial* head, Partial* tail, int n_cu, hipStream_t s, bool line_mode) {
     if (b.n_bytes == 0 || b.n_reads == 0) return hipSuccess;
-    if (line_mode) return launch_tile_variant<8, true, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, 0, s);
+    if (line_mode) {
+        // segments are text lines: the same choice by mean segment length (measured on 3.97 GB of 10 kb records:
+        // 2.63 ms per tokenizer pass with the default kernel, 3.0 ms with VECB); PPQC_LINE_VECB=0|1 forces one
+        const char* lv = getenv("PPQC_LINE_VECB");
+        const bool vecb = lv ? atoi(lv) != 0 : b.n_bytes / b.n_reads < kVecbMeanLen;
+        if (vecb) return launch_tile_variant<8, true, false, true, true>(b, lut_dev, ra, read_base, head, tail, n_cu, 0, s);
+        return launch_tile_variant<8, true, false, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, 0, s);
+    }
     const char* v = getenv("PPQC_TILE_VARIANT");
     const char* bp = getenv("PPQC_TILE_BLOCKS_PER_CU");
     const int bpc = bp ? atoi(bp) : 0;

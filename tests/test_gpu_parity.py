@@ -166,7 +166,9 @@ def test_radix_sort_and_n50(qc, c_oracle):
             got = t.cpu().numpy().view(np.uint32)
             assert np.array_equal(got, np.sort(keys)), n
     for lens in ([2, 2, 2, 3, 3, 4, 8, 8], [10, 20, 30, 40, 50], [5], [0, 0, 0], [7] * 5000,
-                 rng.integers(1, 2_000_000, 70_001).tolist()):
+                 rng.integers(1, 200_000, 7_001).tolist(),
+                 [17_000_000, 5, 300, 70_000, 16_777_216, 1],     # keys with a fourth byte: all four gated passes run
+                 [255, 3, 200], [256, 3, 200], [65_535, 65_536, 9]):   # one, two and three passes
         R = len(lens)
         off = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
         nb = int(off[-1])
@@ -176,6 +178,14 @@ def test_radix_sort_and_n50(qc, c_oracle):
             t = ctx.finalize()
         assert t["n50"] == c_oracle.n50(lens), (lens[:8], t["n50"])
     assert c_oracle.n50([2, 2, 2, 3, 3, 4, 8, 8]) == 8 and c_oracle.n50([10, 20, 30, 40, 50]) == 40
+    # lengths from a table (no bytes behind them): the sort gate is max_len from the extremes kernel, up to 2^32 - 2
+    for lens in ([4_294_967_294, 7, 4_000_000_000, 123_456_789], [16_777_215, 16_777_216, 3], [1]):
+        R = len(lens)
+        with qc.QCContext(device=0, **BASE_CFG) as ctx:
+            ctx.submit_records(np.asarray(lens, np.uint32), np.full(R, 9.0), np.ones(R, np.uint32), np.ones(R, np.uint8),
+                               np.full(R, 1_528_000_000, np.int64))
+            t = ctx.finalize()
+        assert t["n50"] == c_oracle.n50(lens) and t["max_len"] == max(lens), (lens, t["n50"])
 
 
 def test_synth_generator_matches_numpy(qc):
