@@ -388,6 +388,17 @@ def test_table_views_equal_copies(qc):
             assert int(want["totals"][0]) == n
 
 
+def test_boundary_fuzz_both_tile_kernels():
+    """tools/fuzz_parity.py, 12 cases: length distributions that stress read boundaries (runs of tiny reads, reads
+    ending on vector / span / tile edges, reads of several tiles) through both tile-kernel instantiations and three
+    tile sizes, per-read integers bit-exact against the C oracle."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "12", "4242"],
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_malformed_device_csr_fails_loudly_without_faulting(qc):
     """A device batch cannot be validated on the host; bad offsets must neither fault nor pass."""
     import torch
