@@ -159,7 +159,8 @@ typedef struct ppqc_device_tables {
     void* sum_buf; uint64_t n_sum;
     void* max_buf; uint64_t n_max;   /* [0] = max_len, [1..] = chan_max_len */
     void* min_buf; uint64_t n_min;   /* [0] = ~min_pos_len, [1..] = ~chan_min_len */
-    void* lengths; uint64_t n_lengths; /* uint32 per read (0 for bad-channel / flagged reads): N50 input */
+    void* lengths; uint64_t n_lengths; /* uint32 per read (0 for bad-channel / flagged reads): N50 input; complete after
+                                          ppqc_finalize_extremes */
     /* offsets (in u64 elements) of each table inside sum_buf */
     uint64_t off_totals, off_len_log2, off_len_lin, off_q_hist, off_gc_hist, off_hour_reads, off_hour_bases,
         off_chan_reads, off_chan_bases, off_chan_fail, off_cmh_reads, off_cmh_bases;

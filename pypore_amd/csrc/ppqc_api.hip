@@ -94,8 +94,9 @@ struct ppqc_ctx {
 
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> ev_pool;
-    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr, ev_max = nullptr;
-    uint64_t* maxlen_host = nullptr;   // pinned word: max_len lands here right after the extremes kernel
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
+    hipEvent_t ev_max = nullptr;   // behind the extremes kernel: fork point of the sort chain when lens32 comes from it
+    uint64_t* maxlen_host = nullptr;   // a few pinned scratch words (line count of the GPU tokenizer)
     ppqc_timing timing{};
 };
 
