@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpypore_qc.so")
+# PPQC_LIB_PATH: another build of the same library, for A/B measurements of two builds on one box
+LIB_PATH = os.environ.get("PPQC_LIB_PATH") or os.path.join(_HERE, "libpypore_qc.so")
 
 N_TOTALS = 16
 N_LEN_LOG2 = 40

@@ -113,6 +113,7 @@ struct Walk {
     uint64_t r;    // current read
     uint64_t rs;   // its first byte
     uint64_t re;   // one past its last byte
+    uint32_t re_rel;   // min(re - tile_start, 2^31 - 1): what the per-span tests compare (32-bit scalar compares)
     uint64_t re2;  // SOFF: offsets[min(r + 2, R)], requested one read ahead through the scalar cache
     bool done;     // no read left
     // window of upcoming read ends, one per lane: lane i holds offsets[win_r0 + 1 + i] (the end of read win_r0 + i)
@@ -143,11 +144,20 @@ __device__ __forceinline__ uint64_t find_read(const uint64_t* __restrict__ off, 
     return lo;
 }
 
+// Wave-reduce the per-lane sums of a finished read (or tile partial) and store them.  Everything is reduced as u32:
+// per lane and tile gcs, n <= 2^10 and qb <= 2^18, and the error sum (< 2^62 per lane) goes in three 21-bit pieces
+// whose wave sums stay below 2^27.  S = E0 + E1 * 2^21 + E2 * 2^42 is stored as lo = E0 + (E1 << 21), hi = E2 << 10
+// (S = hi * 2^32 + lo; finalize_reads normalises the split).
 __device__ __forceinline__ void flush(Acc& acc, int lane, uint64_t* cnt, uint64_t* hi, uint64_t* lo) {
-    const uint64_t pk = wave_sum_u64(pack_cnt(acc.gcs, acc.n, acc.qb));
-    const uint64_t h = wave_sum_u64(acc.err >> 32);
-    const uint64_t l = wave_sum_u64(acc.err & 0xffffffffull);
-    if (lane == 0) { *cnt = pk; *hi = h; *lo = l; }
+    const uint32_t G = wave_sum_u32(acc.gcs), N = wave_sum_u32(acc.n), Q = wave_sum_u32(acc.qb);
+    const uint32_t E0 = wave_sum_u32((uint32_t)acc.err & 0x1FFFFFu);
+    const uint32_t E1 = wave_sum_u32((uint32_t)(acc.err >> 21) & 0x1FFFFFu);
+    const uint32_t E2 = wave_sum_u32((uint32_t)(acc.err >> 42));
+    if (lane == 0) {
+        *cnt = pack_cnt(G, N, Q);
+        *hi = (uint64_t)E2 << 10;
+        *lo = (uint64_t)E0 + ((uint64_t)E1 << 21);
+    }
     acc = Acc{0, 0, 0, 0};
 }
 
@@ -182,6 +192,11 @@ __device__ __forceinline__ uint64_t read_end(Walk& w, const TileCtx& c, uint64_t
     return readlane_u64(w.win, (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r - w.win_r0)));
 }
 
+__device__ __forceinline__ uint32_t rel_end(uint64_t e, uint64_t tile_start) {
+    const uint64_t d = e - tile_start;   // e > tile_start for the read the walk is in
+    return d > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)d;
+}
+
 template <bool WIN, bool SOFF = false>
 __device__ __forceinline__ void walk_advance(Walk& w, const TileCtx& c) {
     w.rs = w.re;
@@ -196,13 +211,14 @@ __device__ __forceinline__ void walk_advance(Walk& w, const TileCtx& c) {
         w.done = r >= c.R;
         if (!w.done) {
             w.re = e;
+            w.re_rel = rel_end(e, c.tile_start);
             w.re2 = sload_u64(c.off, r + 2 < c.R ? r + 2 : c.R);
         }
         return;
     }
     while (r < c.R) {
         const uint64_t e = WIN ? read_end(w, c, r) : uniform_u64(c.off[r + 1]);
-        if (e != w.rs) { w.re = e; break; }   // skip empty reads
+        if (e != w.rs) { w.re = e; w.re_rel = rel_end(e, c.tile_start); break; }   // skip empty reads
         ++r;
     }
     w.r = r;
@@ -248,14 +264,15 @@ __device__ __noinline__ CutBytes cut_lane_bytes(uint4 vb, uint4 vq, int lb, int 
     return r;
 }
 
-__device__ __forceinline__ void boundaries_bytepar(const uint4& vb, const uint4& vq, const Acc& tot, uint64_t span_base,
-                                                   uint64_t span_end, Walk& w, Acc& acc, const TileCtx& c) {
+__device__ __forceinline__ void boundaries_bytepar(const uint4& vb, const uint4& vq, const Acc& tot, uint32_t span_rel,
+                                                   Walk& w, Acc& acc, const TileCtx& c) {
+    const uint32_t span_end_rel = span_rel + kSpan;
     int prev_lb = -1, o_prev = 0;   // lane and byte offset of the last cut handled in this span
     const int jj = c.lane & 15;
     const bool low32 = c.lane < 32;
     CutBytes cb{0, 0, 0, 0};
     do {
-        const int x = (int)(uint32_t)(w.re - span_base);   // 0 .. kSpan-1, wave-uniform
+        const int x = (int)(w.re_rel - span_rel);   // 0 .. kSpan-1, wave-uniform
         const int lb = x >> 4, o = x & 15;
         if (lb == prev_lb) {
             // the read began in this very vector: it is bytes [o_prev, o) of lane lb, nothing else (cb is still valid)
@@ -276,10 +293,10 @@ __device__ __forceinline__ void boundaries_bytepar(const uint4& vb, const uint4&
         } else {   // cut on a vector boundary: lane lb goes in whole with the lanes behind it
             prev_lb = lb - 1; o_prev = 0;
         }
-    } while (!w.done && w.re < span_end);
+    } while (!w.done && w.re_rel < span_end_rel);
     if (!w.done) {
         if (c.lane > prev_lb) acc_add(acc, tot);   // the rest of the span belongs to the open read
-        if (w.re == span_end) {
+        if (w.re_rel == span_end_rel) {
             flush_read(acc, w, c);
             walk_advance<false, true>(w, c);
         }
@@ -362,6 +379,7 @@ __device__ __forceinline__ bool boundary_rounds(const uint4& vb, const uint4& vq
     if (!w.done) {
         const uint64_t d = w.r - w.win_r0;
         w.re = (w.win_ok && w.r >= w.win_r0 && d < 64) ? readlane_u64(w.win, (int)d) : uniform_u64(c.off[w.r + 1]);
+        w.re_rel = rel_end(w.re, c.tile_start);
     }
     return ok;
 }
@@ -373,8 +391,9 @@ __device__ __forceinline__ void process_span(const uint4& vb, const uint4& vq, u
                                              const TileCtx& c) {
     const uint32_t span_rel = sp * kSpan;
     const uint64_t span_end = c.tile_start + span_rel + kSpan;   // end of the FULL span
+    const uint32_t span_end_rel = span_rel + kSpan;
     Acc tot;
-    if (LINE && w.re >= span_end) {
+    if (LINE && w.re_rel >= span_end_rel) {
         // segments are text lines, line number mod 4 = header / sequence / '+' / quality (wave-uniform): only the
         // sums fastq_finalize reads are kept exact; header and '+' lines cost no arithmetic at all
         const uint32_t ty = (uint32_t)w.r & 3u;
@@ -384,14 +403,14 @@ __device__ __forceinline__ void process_span(const uint4& vb, const uint4& vq, u
     } else {
         tot = vec_sums(vb, vq, c.lut);
     }
-    if (w.re >= span_end) {
+    if (w.re_rel >= span_end_rel) {
         acc_add(acc, tot);
-        if (w.re == span_end) {
+        if (w.re_rel == span_end_rel) {
             flush_read(acc, w, c);
             walk_advance<VECB, !VECB>(w, c);
         }
     } else if (!VECB) {
-        boundaries_bytepar(vb, vq, tot, c.tile_start + span_rel, span_end, w, acc, c);
+        boundaries_bytepar(vb, vq, tot, span_rel, w, acc, c);
     } else {
         // one or more reads end strictly inside this span (or the data ends inside it)
         Acc prev{0, 0, 0, 0};
@@ -486,6 +505,7 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
         w.done = false;
         w.win = 0; w.win_r0 = 0; w.win_ok = false;
         w.re = VECB ? read_end(w, c, w.r) : uniform_u64(c.off[w.r + 1]);
+        w.re_rel = rel_end(w.re, tile_start);
         w.re2 = 0;
         if (!VECB) w.re2 = sload_u64(c.off, w.r + 2 < c.R ? w.r + 2 : c.R);
         Acc acc{0, 0, 0, 0};
@@ -526,7 +546,7 @@ __global__ __launch_bounds__(256, (VECB ? 3 : 4)) void tile_kernel(BatchView b, 
 // Line mode (FASTQ text): one stream.  8 spans per batch at 5 waves per SIMD (95 VGPRs); 16 spans spill (measured
 // 1.0 TB/s of text against 1.27 TB/s for the whole tokenizer path).
 template <int NB, bool VECB>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, (VECB ? 4 : 5))
 void tile_kernel_line(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra, uint64_t read_base,
                       Partial* __restrict__ head, Partial* __restrict__ tail, uint64_t n_tiles) {
     tile_body<NB, true, false, true, VECB>(b, lut_g, ra, read_base, head, tail, n_tiles);
