@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PPQC_ABI_VERSION 2
+#define PPQC_ABI_VERSION 3
 
 enum {
     PPQC_OK = 0,
