@@ -183,7 +183,7 @@ static int input_errors(const uint64_t* e) {
     return PPQC_OK;
 }
 
-static int mark_tail(ppqc_ctx* c) {
+static int mark_busy(ppqc_ctx* c) {
     c->res_busy = true;
     return PPQC_OK;
 }
@@ -672,7 +672,7 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     HIPCHK(launch_extremes(c->ra, c->n_reads, c->tp, c->max_buf, c->min_buf, c->tminmax, !c->lens_early, s));
     if (!c->lens_early) HIPCHK(hipEventRecord(c->ev_max, s));   // fork point of the sort + N50 chain (ppqc_finalize_n50)
     c->state = 1;
-    return mark_tail(c);
+    return mark_busy(c);
 }
 
 int ppqc_time_range(ppqc_ctx* c, int64_t* out2) {
@@ -720,7 +720,7 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
     }
     HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, c->max_buf, s));
     c->state = 2;
-    return mark_tail(c);
+    return mark_busy(c);
 }
 
 static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, bool early_fetch) {
@@ -761,7 +761,7 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     }
     HIPCHK(hipEventRecord(c->ev_t1, s));
     c->state = 3;
-    return mark_tail(c);
+    return mark_busy(c);
 }
 
 int ppqc_finalize_n50(ppqc_ctx* c, const uint32_t* dlens, uint64_t n) { return finalize_n50_impl(c, dlens, n, false); }
@@ -853,7 +853,7 @@ int ppqc_n50_select_hist(ppqc_ctx* c, int round) {
         HIPCHK(hipEventRecord(c->ev_join, ss));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
-    return mark_tail(c);
+    return mark_busy(c);
 }
 
 int ppqc_n50_select_pick(ppqc_ctx* c, int round) {
@@ -869,7 +869,7 @@ int ppqc_n50_select_pick(ppqc_ctx* c, int round) {
         HIPCHK(hipEventRecord(c->ev_t1, c->stream));
         c->state = 3;
     }
-    return mark_tail(c);
+    return mark_busy(c);
 }
 
 int ppqc_set_stream(ppqc_ctx* c, void* stream, int use_external) {
