@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--time-bins", type=int, default=48)
     ap.add_argument("--seed", type=int, default=20240601)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the short end-to-end (pinned host -> GPU) leg")
     ap.add_argument("--cpu-sample-gbases", type=float, default=0.0, help="0 = auto (2 Gbases prefix)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work timed for the cpu_baseline leg")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config4adv"])
@@ -171,12 +172,58 @@ def main():
                          "traffic": None, "kernel_ms": round(k_ms, 4), "bytes_per_launch": int(alg_bytes)},
         }
         out["roofline"].update(pmc_traffic(int(alg_bytes)))
+        if world == 1 and not a.no_h2d:
+            out["config"]["end_to_end_incl_h2d"] = h2d_leg(a, torch, off, ch, mux, t, d_bases, d_quals, cfg)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, off, d_bases, d_quals, ctx)
         print(json.dumps(out), flush=True)
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def h2d_leg(a, torch, off, ch, mux, t, d_bases, d_quals, cfg):
+    """End to end including H2D on a bounded sample (BASELINE config 5 in small): the first ~2 Gbases of the same reads
+    streamed from pinned host memory as 4000-read batches through the two staging slots of ppqc_submit, tables + N50
+    included.  PCIe-bound; reported beside `value`, never as `value`.  `--stream` runs the whole workload this way."""
+    from pypore_amd import qc
+    r = int(np.searchsorted(off, np.uint64(2_000_000_000), side="right")) - 1
+    r = max(1, min(r, len(off) - 1))
+    nb = int(off[r])
+    pb, pq = qc.PinnedBuffer(nb), qc.PinnedBuffer(nb)
+    torch.from_numpy(pb.array).copy_(d_bases[:nb])
+    torch.from_numpy(pq.array).copy_(d_quals[:nb])
+    torch.cuda.synchronize()
+    cuts = list(range(0, r, a.batch_reads)) + [r]
+    batches = []
+    for k in range(len(cuts) - 1):
+        i, j = cuts[k], cuts[k + 1]
+        s0, s1 = int(off[i]), int(off[j])
+        batches.append((pb.array[s0:s1], pq.array[s0:s1], (off[i:j + 1] - off[i]).astype(np.uint64), ch[i:j], mux[i:j],
+                        t[i:j]))
+    c2 = dict(cfg); c2["max_reads_hint"] = r
+    ctx = qc.QCContext(device=torch.cuda.current_device(), **c2)
+
+    def step():
+        ctx.reset()
+        for k, b in enumerate(batches):
+            ctx.submit(*b, slot=k % 2)
+        return ctx.finalize(copy=False)
+
+    step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    passes = 3
+    for _ in range(passes):
+        tables = step()
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / passes
+    ok = int(tables["totals"][0]) == r and int(tables["totals"][1]) == nb
+    ctx.close(); pb.close(); pq.close()
+    return {"gbases_per_s": round(nb / dt / 1e9, 2), "h2d_GBps": round((2 * nb + 21 * r) / dt / 1e9, 2),
+            "sample": "first %d reads (%.2f Gbases) in %d batches of %d reads from pinned host memory, two staging "
+                      "slots, tables + N50 included, %d passes" % (r, nb / 1e9, len(batches), a.batch_reads, passes),
+            "totals_ok": bool(ok)}
 
 
 def stream_mode(a, ctx, torch, off, ch, mux, t, d_bases, d_quals, n_bytes, R):
