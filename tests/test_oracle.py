@@ -220,3 +220,37 @@ def test_nano_layout_is_the_minion_32x16_map():
     assert rows[0] == [str(x) for x in (1, 2, 3, 4, 5, 6, 7, 8, 40, 39, 38, 37, 36, 35, 34, 33)]        # seq_routines.py:589
     assert rows[4][:3] == ["449", "450", "451"] and rows[4][8] == "488"                                  # :593
     assert rows[31] == [str(x) for x in (89, 90, 91, 92, 93, 94, 95, 96, 128, 127, 126, 125, 124, 123, 122, 121)]  # :670
+
+
+def test_constants_pinned_to_the_reference_source():
+    """tests/golden/reference_constants.json holds the data constants the reference hard-codes on this path, extracted
+    from its source text by tests/golden/make_reference_constants.py (the one anchor this build has in the reference
+    itself, which ships no tests): the oracle, the host drop-in and the C ABI must agree with them."""
+    import ctypes as C
+    import hashlib
+    import json
+    import os
+    from oracle import pypore_oracle as po
+    from pypore_amd import _lib
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_constants.json")))
+    lay = ref["nano_layout"]
+    import importlib
+    sr = importlib.import_module("pypore_amd.seq_routines")
+    for layout in (po.nano_layout(), sr.nano_layout()):
+        flat = [x for row in layout for x in row]
+        assert (len(layout), len(layout[0]), len(flat)) == (lay["rows"], lay["cols"], lay["count"])
+        assert hashlib.sha256(",".join(flat).encode()).hexdigest() == lay["sha256_of_comma_joined"]
+        assert layout[0] == lay["first_row"] and layout[-1] == lay["last_row"]
+    assert (sr.n_channels, sr.n_hours) == (ref["n_channels"], ref["n_hours"])
+    q, g = ref["quality_hist"], ref["gc_hist"]
+    assert _lib.N_QHIST == (q["end"] - q["start"]) // q["size"] and q["start"] == 6      # bins 6+j <= q < 7+j
+    assert _lib.N_GCHIST == (g["end"] - g["start"]) // g["size"] and g["size"] == 5
+    assert _lib.N_LEN_LIN == ref["length_hist"]["nbinsx"]
+    assert ref["fail_below_q"] == ref["fail_below_q_summary"] == ref["fastq_kept_from_q"] == 7.0
+    assert ref["fail_path_default_q"] == 6.99 and ref["muxes"] == [1, 2, 3, 4]
+    cfg = _lib.Config()
+    lib = _lib.load()
+    assert lib.ppqc_config_default(C.byref(cfg)) == 0
+    assert (cfg.n_channels, cfg.n_mux, cfg.n_time_bins, cfg.fail_q) == (ref["n_channels"], len(ref["muxes"]),
+                                                                       ref["n_hours"], ref["fail_below_q"])
+    assert po.default_config()["fail_q"] == ref["fail_below_q"]
