@@ -13,6 +13,23 @@ REF = "/root/reference/lib"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def cli_options(src):
+    """The option table of lib/seqstats.py:86-116 as data: flags, default, choices, type, nargs of every add_argument."""
+    opts = []
+    for m in re.finditer(r"add_argument\(\s*'(-\w+)',\s*'(--\w+)'(.*?)\)\s*\n\s*(?=[fg]\.add_argument|\n|try:)", src, re.S):
+        short, long_, rest = m.group(1), m.group(2), m.group(3)
+        o = {"short": short, "long": long_}
+        d = re.search(r"default\s*=\s*(\[[^\]]*\]|None|\d+|ldir)", rest)
+        o["default"] = None if not d or d.group(1) == "None" else ("<tmpdir>" if d.group(1) == "ldir" else eval(d.group(1)))
+        c = re.search(r"choices\s*=\s*(\[[^\]]*\]|range\(\d+, \d+\))", rest)
+        o["choices"] = None if not c else [x for x in eval(c.group(1))]
+        o["type"] = "int" if re.search(r"type\s*=\s*int", rest) else None
+        n = re.search(r"nargs\s*=\s*(\d+|\"\?\")", rest)
+        o["nargs"] = None if not n else (int(n.group(1)) if n.group(1).isdigit() else "?")
+        opts.append(o)
+    return opts
+
+
 def main():
     sr = open(os.path.join(REF, "seq_routines.py")).read()
     f5 = open(os.path.join(REF, "fast5_reader.py")).read()
@@ -39,6 +56,8 @@ def main():
         "muxes": list(range(*map(int, re.search(
             r"MuxProductivity = \{str\(il\): \[\] for il in range\((\d+), (\d+)\)\}", f5).groups()))),
     }
+    out["seqstats_cli"] = cli_options(open(os.path.join(REF, "seqstats.py")).read())
+    out["default_output_dir"] = re.search(r"out_dir = '([A-Za-z_]+)'", open(os.path.join(REF, "seqstats.py")).read()).group(1)
     json.dump(out, open(os.path.join(HERE, "reference_constants.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

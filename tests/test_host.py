@@ -250,3 +250,31 @@ def test_html_reports_are_written_with_the_reference_trace_names(tmp_path, monke
     for name in ("ReadNHeat", "BaseNHeat", "Pore1", "Pore4", "% Pass", "plotly_click", "CHANNEL:"):
         assert name in s
     assert not (tmp_path / "lab_sequencing_summary.html").exists()       # moved, lib/seq_routines.py:92, 316
+
+
+def test_cli_surface_matches_the_reference_option_table():
+    """The option table of the reference's lib/seqstats.py:86-116, extracted as data from its source text into
+    tests/golden/reference_constants.json (make_reference_constants.py): every reference option exists here with the
+    same flags, default, choices, type and nargs; the default output directory is the reference's."""
+    import json
+    import os
+    from pypore_amd import seqstats
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_constants.json")))
+    parser = seqstats.build_parser("<tmpdir>")
+    by_long = {}
+    for a in parser._actions:
+        for s in a.option_strings:
+            if s.startswith("--"):
+                by_long[s] = a
+    assert len(ref["seqstats_cli"]) == 9
+    for o in ref["seqstats_cli"]:
+        a = by_long[o["long"]]
+        assert o["short"] in a.option_strings, o
+        if o["long"] == "--help":
+            continue
+        assert a.default == o["default"], (o, a.default)
+        assert (None if a.choices is None else list(a.choices)) == o["choices"], (o, a.choices)
+        assert (a.type is int) == (o["type"] == "int"), o
+        assert a.nargs == o["nargs"], (o, a.nargs)
+    import inspect
+    assert "'%s'" % ref["default_output_dir"] in inspect.getsource(seqstats.ArgsReader)
