@@ -56,6 +56,7 @@ def main():
         "muxes": list(range(*map(int, re.search(
             r"MuxProductivity = \{str\(il\): \[\] for il in range\((\d+), (\d+)\)\}", f5).groups()))),
     }
+    out["output_suffixes"] = sorted(set(re.findall(r"prefix \+ '([._A-Za-z]+)'", sr)))   # :276, :773, :799
     out["seqstats_cli"] = cli_options(open(os.path.join(REF, "seqstats.py")).read())
     out["default_output_dir"] = re.search(r"out_dir = '([A-Za-z_]+)'", open(os.path.join(REF, "seqstats.py")).read()).group(1)
     json.dump(out, open(os.path.join(HERE, "reference_constants.json"), "w"), indent=1)

@@ -278,3 +278,9 @@ def test_cli_surface_matches_the_reference_option_table():
         assert a.nargs == o["nargs"], (o, a.nargs)
     import inspect
     assert "'%s'" % ref["default_output_dir"] in inspect.getsource(seqstats.ArgsReader)
+    # output file names: <label>_sequencing_summary.html, <label>_pore_activity_map.html, <label>.fastq.gz
+    from pypore_amd import seq_routines
+    src = inspect.getsource(seq_routines)
+    assert ref["output_suffixes"] == [".fastq.gz", "_pore_activity_map.html", "_sequencing_summary.html"]
+    for suffix in ref["output_suffixes"]:
+        assert "prefix + '%s'" % suffix in src, suffix
