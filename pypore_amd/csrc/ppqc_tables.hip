@@ -82,6 +82,29 @@ __global__ __launch_bounds__(1024) void extremes_kernel(ReadArrays ra, uint64_t 
     }
 }
 
+// The (channel, mux, hour) cells take two device-scope atomics per read (reads += 1, bases += L), 62 of the kernel's 115 us
+// at 10^6 reads.  When no cell can overflow either field -- n < 2^22 reads and n * max_len < 2^42 bases, decided on the
+// device from the run's max_len -- both go into ONE atomic on the bases cell, the count above bit 42, and
+// cmh_unpack_kernel splits the cells afterwards.  Exact by construction: a cell's count is at most n, its bases at most
+// n * max_len.
+constexpr int kCmhShift = 42;
+__device__ __forceinline__ bool cmh_packable(uint64_t n, uint64_t max_len) {
+    return n < (1ull << (64 - kCmhShift)) && (max_len == 0 || n <= ((1ull << kCmhShift) - 1) / max_len);
+}
+
+__global__ __launch_bounds__(256) void cmh_unpack_kernel(uint64_t* sum_buf, TableLayout lay, uint64_t n,
+                                                         const uint64_t* max_buf) {
+    if (!cmh_packable(n, max_buf[0])) return;
+    const uint64_t cells = (uint64_t)lay.n_channels * lay.n_mux * lay.n_time_bins;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t v = sum_buf[lay.off_cmh_bases + i];
+        if (v) {
+            sum_buf[lay.off_cmh_reads + i] = v >> kCmhShift;
+            sum_buf[lay.off_cmh_bases + i] = v & ((1ull << kCmhShift) - 1);
+        }
+    }
+}
+
 // ---- pass 2: all SUM tables ------------------------------------------------------------------------------------------
 // Dynamic LDS layout (u64 first for alignment):
 //   u64 totals[16] | u64 hour_bases[nb] | u64 chan_bases[nchL] |
@@ -109,6 +132,7 @@ __global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n,
 
     unsigned long long* g = reinterpret_cast<unsigned long long*>(sum_buf);
     const uint64_t lin_w = max_buf[0] / PPQC_N_LEN_LIN + 1;
+    const bool packed = cmh_packable(n, max_buf[0]);
     const bool chan_lds = nchL != 0;
 
     uint64_t tot[PPQC_TOT_BAD_MUX + 1] = {};   // thread-local run totals, added to LDS once at the end
@@ -160,8 +184,12 @@ __global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n,
         atomicAdd(&s_hreads[h], 1u);
         atomicAdd(&s_hbases[h], (unsigned long long)L);
         const uint64_t cell = ((uint64_t)c * nmux + (m - 1)) * nb + (uint32_t)h;
-        atomicAdd(&g[tp.lay.off_cmh_reads + cell], 1ull);
-        atomicAdd(&g[tp.lay.off_cmh_bases + cell], (unsigned long long)L);
+        if (packed) {   // one atomic per read: count in the bits above kCmhShift (cmh_unpack_kernel splits the cells)
+            atomicAdd(&g[tp.lay.off_cmh_bases + cell], (1ull << kCmhShift) | (unsigned long long)L);
+        } else {
+            atomicAdd(&g[tp.lay.off_cmh_reads + cell], 1ull);
+            atomicAdd(&g[tp.lay.off_cmh_bases + cell], (unsigned long long)L);
+        }
     }
 #pragma unroll
     for (int k = 0; k <= PPQC_TOT_BAD_MUX; ++k)
@@ -337,6 +365,8 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
     // 0.317 ms for the whole finalize, 512 x 256: 0.34, 2048 x 256: 0.42; PPQC_TAB_* / PPQC_EXT_* are A/B knobs)
     hipLaunchKernelGGL(tables_kernel, dim3(grid_for(n, env_or("PPQC_TAB_BLOCKS", 256))),
                        dim3(env_or("PPQC_TAB_THREADS", 512)), lds, s, ra, n, tp, sum_buf, max_buf, nchL);
+    const uint64_t cells = (uint64_t)tp.lay.n_channels * tp.lay.n_mux * tp.lay.n_time_bins;
+    hipLaunchKernelGGL(cmh_unpack_kernel, dim3(grid_for(cells, 512)), dim3(256), 0, s, sum_buf, tp.lay, n, max_buf);
     return hipGetLastError();
 }
 

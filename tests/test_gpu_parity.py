@@ -278,6 +278,31 @@ def test_records_path_sequencing_summary_rows(qc, c_oracle, mode):
                                             mux[small], t[small], None, cfg), "records vs python oracle")
 
 
+def test_cell_tables_on_both_sides_of_the_packing_bound(qc, c_oracle):
+    """tables_kernel packs a cell's read count and bases into one atomic when n < 2^22 and n * max_len < 2^42 (decided on
+    the device); otherwise two atomics.  Lengths from a table reach both sides with few reads: the cell tables (and
+    everything else) must equal the oracle's either way, also with every read in ONE cell."""
+    cfg = dict(BASE_CFG, n_mux=1, time_mode=0, n_channels=16)
+    n = 3000
+    for top in (60_000, (1 << 42) // n - 1, (1 << 42) // n + 2, 4_294_967_294):
+        length, mean_q, gc, channel, mux, t = _record_columns(91, n, 16)
+        rng = np.random.default_rng(int(top) % 9973)
+        length = rng.integers(0, min(top, 4_294_967_294) + 1, n).astype(np.uint64)
+        length[0] = top                                        # max_len is exactly `top`
+        length = length.astype(np.uint32)
+        gc = np.zeros(n, np.uint32)
+        for one_cell in (False, True):
+            ch = np.full(n, 3, np.uint32) if one_cell else channel
+            tt = np.full(n, 1_528_000_000 + 5 * 3600, np.int64) if one_cell else t
+            with qc.QCContext(device=0, **cfg) as ctx:
+                ctx.submit_records(length, mean_q, ch, mux, tt, gc)
+                tables = ctx.finalize()
+            wt = c_oracle.tables(_record_stats(length, mean_q, gc), ch, mux, tt, None, cfg)
+            assert_tables_equal(tables, wt, "top %d one_cell %s" % (top, one_cell))
+            if one_cell:
+                assert int(tables["cmh_reads"][2, 0, 5]) == n and int(tables["cmh_bases"][2, 0, 5]) == int(length.astype(np.uint64).sum())
+
+
 def test_records_and_csr_batches_mix_in_one_run(qc, c_oracle):
     b = random_batch(71, 1200, 400)
     length, mean_q, gc, channel, mux, t = _record_columns(72, 900, 512, hours=48)
