@@ -78,7 +78,8 @@ struct ppqc_ctx {
     int state = 0;   // 0 reads only, 1 extremes done, 2 tables done, 3 n50 done
     bool lens_early = true;    // every read of the run came through finalize_reads: lens32 and the sort gate are ready
     hipEvent_t ev_reads = nullptr;   // behind the last finalize_reads of the run
-    bool sum_fetched = false;   // ppqc_finalize: the SUM tables were copied to res_host behind the tables kernel
+    bool sum_fetched = false;   // ppqc_finalize: everything but the N50 was copied to res_host behind the tables kernel,
+                                // and the N50 kernels write their result into res_host themselves
     uint64_t n50 = 0;
 
     // sort / mode-1 scratch
@@ -158,6 +159,8 @@ static int ensure_sort32(ppqc_ctx* c, uint64_t n) {
     CHK(grow(&c->sk32_tmp, 0, cap, c->stream));
     CHK(grow(&c->counts, 0, sort_count_words(cap) + 1024, c->stream));
     CHK(grow(&c->n50_blocks, 0, n50_block_words(cap), c->stream));
+    HIPCHK(hipMemsetAsync(c->n50_blocks, 0, 8, c->stream));   // the N50 kernel's ticket counter: zero between launches
+    HIPCHK(hipStreamSynchronize(c->stream));                  // the kernel may run on the auxiliary stream
     c->cap_sort32 = cap;
     return PPQC_OK;
 }
@@ -745,14 +748,19 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     if (ss != s) HIPCHK(hipStreamWaitEvent(ss, early ? c->ev_reads : c->ev_max, 0));
     HIPCHK(hipEventRecord(c->ev_s0, ss));
     HIPCHK(sort_u32_gated(dlens, c->sk32, c->sk32_tmp, n, c->counts, gate, gate_words, ss));
-    HIPCHK(launch_n50_gated(dlens, c->sk32, c->sk32_tmp, gate, gate_words, n, c->n50_blocks, c->n50_out, ss));
+    // ppqc_finalize: everything the host needs except the N50 is final once the tables kernel is done.  It is copied to
+    // the pinned mirror on the main stream now, beside the sort chain (1.6 MB at 512x4x48), and the N50 kernels write
+    // their result straight into the mirror, so ppqc_fetch_tables only has to wait for the join: no copy behind it.
+    // The N50 word of the mirror lies outside the copied range (the spare word behind the error words), so the copy,
+    // which carries the device's not yet final n50_out along, cannot overwrite it.
+    const bool early_out = early_fetch && c->state == 2 && ss != s;
+    HIPCHK(launch_n50_gated(dlens, c->sk32, c->sk32_tmp, gate, gate_words, n, c->n50_blocks, c->n50_out,
+                            early_out ? c->res_host + c->res_words + 3 : nullptr, ss));
     c->sort_end = c->ev_s1;
     if (ss == s) HIPCHK(hipEventRecord(c->ev_s1, ss));
     if (ss != s) {
-        if (early_fetch && c->state == 2) {
-            // the SUM tables are final once the tables kernel is done: their copy to the host (1.6 MB at 512x4x48)
-            // goes on the main stream now, beside the sort chain, and ppqc_fetch_tables only adds the few KB behind them
-            HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, c->tp.lay.n_sum * 8, hipMemcpyDeviceToHost, s));
+        if (early_out) {
+            HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, (c->res_words + 3) * 8, hipMemcpyDeviceToHost, s));
             c->sum_fetched = true;
         }
         HIPCHK(hipEventRecord(c->ev_join, ss));   // also the end of the sort timing
@@ -772,9 +780,9 @@ static int fetch_tables_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
     HIPCHK(hipSetDevice(c->device));
     const TableLayout& l = c->tp.lay;
     // stream-ordered behind the last finalize kernel: one host synchronisation for the whole step
-    const uint64_t skip = c->sum_fetched ? c->tp.lay.n_sum : 0;
-    HIPCHK(hipMemcpyAsync(c->res_host + skip, c->res_buf + skip, (c->res_words + 3 - skip) * 8, hipMemcpyDeviceToHost,
-                          c->stream));
+    const bool n50_in_mirror = c->sum_fetched;
+    if (!c->sum_fetched)
+        HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, (c->res_words + 3) * 8, hipMemcpyDeviceToHost, c->stream));
     c->sum_fetched = false;
     CHK(ppqc_sync(c));
     {   // the device keeps the minima complemented (one all-reduce MAX merges maxima and minima): decode in place
@@ -800,7 +808,7 @@ static int fetch_tables_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
     o->max_len = mx[0];
     o->min_pos_len = mn[0];
     o->lin_bin_width = mx[0] / PPQC_N_LEN_LIN + 1;
-    o->n50 = c->n50 = (mn + 1 + nch)[2];
+    o->n50 = c->n50 = n50_in_mirror ? h[c->res_words + 3] : (mn + 1 + nch)[2];
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1) == hipSuccess) c->timing.finalize_ms_last = ms;
     if (hipEventElapsedTime(&ms, c->ev_s0, c->sort_end ? c->sort_end : c->ev_s1) == hipSuccess) c->timing.sort_ms_last = ms;

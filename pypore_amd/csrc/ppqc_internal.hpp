@@ -122,7 +122,8 @@ uint64_t n50_block_words(uint64_t n);
 hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s);
 // after sort_u32_gated(in, buf_a, buf_b, .., gate): picks the buffer the sorted keys ended in from the same gate word
 hipError_t launch_n50_gated(const uint32_t* in, const uint32_t* buf_a, const uint32_t* buf_b, const uint64_t* gate,
-                            int gate_words, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s);
+                            int gate_words, uint64_t n, uint64_t* block_sums, uint64_t* out, uint64_t* host_out,
+                            hipStream_t s);   // host_out: optional pinned host word that also receives the N50
 
 // Exact N50 by MSD radix select (multi-GPU path).  state = {prefix, weight of all longer keys}; sel = PPQC_N_SEL u64.
 // hist: sel[d] += sum of the lengths whose bits above `shift + nbits` equal the prefix and whose digit is d.

@@ -219,7 +219,7 @@ hipError_t sort_u64_pairs(uint64_t* keys, uint64_t* tmp_keys, uint32_t* vals, ui
 constexpr int kN50Items = 8;
 constexpr int kN50Block = 256 * kN50Items;
 
-uint64_t n50_block_words(uint64_t n) { return (n + kN50Block - 1) / kN50Block + 2; }
+uint64_t n50_block_words(uint64_t n) { return (n + kN50Block - 1) / kN50Block + 2; }   // [0] ticket counter, then the sums
 
 // Which buffer holds the sorted keys after a gated sort (see sort_u32_gated); without a gate it is `a`.
 __device__ __forceinline__ const uint32_t* gated_pick(const uint32_t* a, const uint32_t* b, const uint64_t* gate,
@@ -231,68 +231,89 @@ __device__ __forceinline__ const uint32_t* gated_pick(const uint32_t* a, const u
     return (top & 1) ? b : a;
 }
 
-__global__ __launch_bounds__(256) void n50_blocksum_kernel(const uint32_t* __restrict__ sa,
-                                                           const uint32_t* __restrict__ sb,
-                                                           const uint64_t* __restrict__ gate, int gate_words,
-                                                           const uint32_t* __restrict__ in, uint64_t n,
-                                                           uint64_t* __restrict__ bsum) {
+// One kernel.  Every block writes the sum of its 2048 keys and takes a ticket; the block that draws the last ticket has
+// all sums behind its fence, scans them from the top (256 threads, a segment each), finds the block the N50 lies in and
+// searches that block's keys.  ws[0] is the ticket counter (zero between launches: the last block puts it back),
+// ws[1 + b] the sum of block b.  `host_out` (may be null): a pinned host word that receives the N50 as well, so that a
+// caller who has everything else on the host already needs no copy behind this kernel.
+__global__ __launch_bounds__(256) void n50_kernel(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ sb,
+                                                  const uint64_t* __restrict__ gate, int gate_words,
+                                                  const uint32_t* __restrict__ in, uint64_t n, uint64_t* ws,
+                                                  uint32_t nblocks, uint64_t* __restrict__ out,
+                                                  uint64_t* __restrict__ host_out) {
     const uint32_t* __restrict__ s = gated_pick(sa, sb, gate, gate_words, in, n);
-    __shared__ unsigned long long acc;
-    if (threadIdx.x == 0) acc = 0;
-    __syncthreads();
-    const uint64_t b0 = (uint64_t)blockIdx.x * kN50Block;
-    uint64_t t = 0;
-    for (int k = 0; k < kN50Items; ++k) {
-        const uint64_t i = b0 + (uint64_t)k * 256 + threadIdx.x;
-        if (i < n) t += s[i];
-    }
-    t = wave_sum_u64(t);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&acc, (unsigned long long)t);
-    __syncthreads();
-    if (threadIdx.x == 0) bsum[blockIdx.x] = acc;
-}
-
-// Single block: bsum[b] <- sum of the blocks after b (exclusive suffix); out[1] = total.
-__global__ __launch_bounds__(256) void n50_scan_kernel(uint64_t* __restrict__ bsum, uint64_t nblocks,
-                                                       uint64_t* __restrict__ out) {
     __shared__ uint64_t part[256];
+    __shared__ unsigned long long acc;
+    __shared__ uint64_t s_total, s_after;
+    __shared__ uint32_t s_blk, s_last;
     const uint32_t t = threadIdx.x;
-    const uint64_t seg = (nblocks + 255) / 256;
-    const uint64_t b = t * seg, e = b + seg < nblocks ? b + seg : nblocks;
-    uint64_t s = 0;
-    for (uint64_t i = b; i < e; ++i) s += bsum[i];
-    part[t] = s;
+    if (t == 0) acc = 0;
+    __syncthreads();
+    {
+        const uint64_t b0 = (uint64_t)blockIdx.x * kN50Block;
+        uint32_t v[kN50Items];
+#pragma unroll
+        for (int k = 0; k < kN50Items; ++k) {
+            const uint64_t i = b0 + (uint64_t)k * 256 + t;
+            v[k] = i < n ? s[i] : 0u;
+        }
+        uint64_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < kN50Items; ++k) sum += v[k];
+        sum = wave_sum_u64(sum);
+        if ((t & 63) == 0) atomicAdd(&acc, (unsigned long long)sum);
+    }
     __syncthreads();
     if (t == 0) {
-        uint64_t run = 0;
-        for (int i = 255; i >= 0; --i) { const uint64_t v = part[i]; part[i] = run; run += v; }
-        out[1] = run;
-        out[0] = 0;
+        __hip_atomic_store(&ws[1 + blockIdx.x], (uint64_t)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned long long ticket = atomicAdd((unsigned long long*)&ws[0], 1ull);
+        s_last = ticket == (unsigned long long)nblocks - 1ull;
     }
     __syncthreads();
-    uint64_t run = part[t];
-    for (uint64_t i = e; i > b; --i) { const uint64_t v = bsum[i - 1]; bsum[i - 1] = run; run += v; }
-}
-
-__global__ __launch_bounds__(256) void n50_find_kernel(const uint32_t* __restrict__ sa,
-                                                       const uint32_t* __restrict__ sb,
-                                                       const uint64_t* __restrict__ gate, int gate_words,
-                                                       const uint32_t* __restrict__ in, uint64_t n,
-                                                       const uint64_t* __restrict__ bsuf, uint64_t* __restrict__ out) {
-    const uint32_t* __restrict__ s = gated_pick(sa, sb, gate, gate_words, in, n);
-    __shared__ uint64_t part[256];
-    const uint64_t total = out[1];
-    if (total == 0) return;
-    const uint32_t t = threadIdx.x;
-    const uint64_t b0 = (uint64_t)blockIdx.x * kN50Block + (uint64_t)t * kN50Items;   // thread owns 8 consecutive keys
-    uint32_t v[kN50Items];
+    if (!s_last) return;
+    __threadfence();
+    const uint32_t seg = (nblocks + 255) / 256;
+    const uint32_t b = t * seg < nblocks ? t * seg : nblocks, e = b + seg < nblocks ? b + seg : nblocks;
     uint64_t loc = 0;
-#pragma unroll
-    for (int k = 0; k < kN50Items; ++k) { const uint64_t i = b0 + k; v[k] = i < n ? s[i] : 0; loc += v[k]; }
+    for (uint32_t i = b; i < e; ++i) loc += __hip_atomic_load(&ws[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     part[t] = loc;
     __syncthreads();
     if (t == 0) {
-        uint64_t run = bsuf[blockIdx.x];
+        uint64_t run = 0;
+        for (int i = 255; i >= 0; --i) { const uint64_t x = part[i]; part[i] = run; run += x; }
+        s_total = run;
+        s_blk = 0;
+        s_after = 0;
+        out[1] = run;
+        out[0] = 0;
+        if (host_out) host_out[0] = 0;
+        __hip_atomic_store(&ws[0], (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    const uint64_t total = s_total;
+    if (total == 0) return;
+    {   // the block whose keys carry the running sum from the top across half the total
+        uint64_t after = part[t];
+        for (uint32_t i = e; i > b; --i) {
+            const uint64_t x = __hip_atomic_load(&ws[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // block i - 1
+            const uint64_t suf = after + x;
+            if (2 * suf >= total && 2 * after < total) { s_blk = i - 1; s_after = after; }
+            after = suf;
+        }
+    }
+    __syncthreads();
+    const uint64_t b0 = (uint64_t)s_blk * kN50Block + (uint64_t)t * kN50Items;   // thread owns 8 consecutive keys
+    uint32_t v[kN50Items];
+    loc = 0;
+#pragma unroll
+    for (int k = 0; k < kN50Items; ++k) { const uint64_t i = b0 + k; v[k] = i < n ? s[i] : 0; loc += v[k]; }
+    const uint64_t blk_after = s_after;
+    __syncthreads();
+    part[t] = loc;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t run = blk_after;
         for (int i = 255; i >= 0; --i) { const uint64_t x = part[i]; part[i] = run; run += x; }
     }
     __syncthreads();
@@ -302,26 +323,33 @@ __global__ __launch_bounds__(256) void n50_find_kernel(const uint32_t* __restric
         const uint64_t i = b0 + k;
         const uint64_t suf = after + v[k];
         // predicate true at i, false at i+1 (or i is the last key)
-        if (i < n && 2 * suf >= total && (i + 1 == n || 2 * after < total)) out[0] = v[k];
+        if (i < n && 2 * suf >= total && (i + 1 == n || 2 * after < total)) {
+            out[0] = v[k];
+            if (host_out) host_out[0] = v[k];
+        }
         after = suf;
     }
 }
 
 static hipError_t n50_launch(const uint32_t* sa, const uint32_t* sb, const uint64_t* gate, int gate_words,
-                             const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
-    if (n == 0) return hipMemsetAsync(out, 0, 16, s);
+                             const uint32_t* in, uint64_t n, uint64_t* block_sums, uint64_t* out, uint64_t* host_out,
+                             hipStream_t s) {
+    if (n == 0) {
+        if (host_out) host_out[0] = 0;   // nothing in flight writes it
+        return hipMemsetAsync(out, 0, 16, s);
+    }
     const uint64_t nblocks = (n + kN50Block - 1) / kN50Block;
-    hipLaunchKernelGGL(n50_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sa, sb, gate, gate_words, in, n, block_sums);
-    hipLaunchKernelGGL(n50_scan_kernel, dim3(1), dim3(256), 0, s, block_sums, nblocks, out);
-    hipLaunchKernelGGL(n50_find_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sa, sb, gate, gate_words, in, n, block_sums, out);
+    hipLaunchKernelGGL(n50_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sa, sb, gate, gate_words, in, n, block_sums,
+                       (uint32_t)nblocks, out, host_out);
     return hipGetLastError();
 }
 hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
-    return n50_launch(sorted, nullptr, nullptr, 1, sorted, n, block_sums, out, s);
+    return n50_launch(sorted, nullptr, nullptr, 1, sorted, n, block_sums, out, nullptr, s);
 }
 hipError_t launch_n50_gated(const uint32_t* in, const uint32_t* buf_a, const uint32_t* buf_b, const uint64_t* gate,
-                            int gate_words, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
-    return n50_launch(buf_a, buf_b, gate, gate_words, in, n, block_sums, out, s);
+                            int gate_words, uint64_t n, uint64_t* block_sums, uint64_t* out, uint64_t* host_out,
+                            hipStream_t s) {
+    return n50_launch(buf_a, buf_b, gate, gate_words, in, n, block_sums, out, host_out, s);
 }
 
 // ---- N50 by weighted radix select (multi-GPU: only PPQC_N_SEL-word histograms cross xGMI) --------------------------
