@@ -178,6 +178,24 @@ def test_radix_sort_and_n50(qc, c_oracle):
             t = ctx.finalize()
         assert t["n50"] == c_oracle.n50(lens), (lens[:8], t["n50"])
     assert c_oracle.n50([2, 2, 2, 3, 3, 4, 8, 8]) == 8 and c_oracle.n50([10, 20, 30, 40, 50]) == 40
+    # the N50 kernel's block structure (2048 keys a block): one block, block edges, the N50 in the top block, in a
+    # middle block, behind whole blocks of zeros; twice per context: the ticket counter must be back at zero
+    for n, kind in [(1, "flat"), (2047, "flat"), (2048, "flat"), (2049, "flat"), (4096, "top"), (4097, "top"),
+                    (300_001, "flat"), (300_001, "top"), (300_001, "zeros"), (2048 * 257 + 5, "flat")]:
+        if kind == "flat":
+            lens = np.full(n, 1000, np.uint32) + (np.arange(n) % 7).astype(np.uint32)
+        elif kind == "top":                                   # one key carries more than half the total
+            lens = np.full(n, 3, np.uint32)
+            lens[n // 2] = 3 * n + 10
+        else:                                                 # mostly zeros: the sorted array begins with empty blocks
+            lens = np.zeros(n, np.uint32)
+            lens[::1000] = 5000 + np.arange(len(lens[::1000]), dtype=np.uint32)
+        with qc.QCContext(device=0, **BASE_CFG) as ctx:
+            for _ in range(2):
+                ctx.reset()
+                ctx.submit_records(lens, np.full(n, 9.0), np.ones(n, np.uint32), np.ones(n, np.uint8),
+                                   np.full(n, 1_528_000_000, np.int64))
+                assert ctx.finalize()["n50"] == c_oracle.n50(lens), (n, kind)
     # lengths from a table (no bytes behind them): the sort gate is max_len from the extremes kernel, up to 2^32 - 2
     for lens in ([4_294_967_294, 7, 4_000_000_000, 123_456_789], [16_777_215, 16_777_216, 3], [1]):
         R = len(lens)
