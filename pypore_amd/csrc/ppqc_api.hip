@@ -57,6 +57,9 @@ struct ppqc_ctx {
     hipStream_t aux = nullptr;      // the sort + N50 chain runs here, beside the tables kernel on `stream`
     hipEvent_t ev_join = nullptr, ev_init = nullptr;
     bool init_on_aux = false;   // the last clear of the result buffer went to the auxiliary stream
+    bool res_clean = false;  // ppqc_reset cleared the result buffer on the main stream and nothing has used it since
+    hipEvent_t fin_start = nullptr, sort_start = nullptr;   // start events of the finalize / sort timings of this step
+    bool end_split = false;  // the finalize ended on two streams: its end is the later of ev_t1 and sort_end
     bool res_busy = false;   // a finalize phase (or a caller's collective on the tables) may still run: set by every
                              // finalize phase, cleared when the stream has been synchronised
     hipEvent_t last_a = nullptr, sort_end = nullptr;   // start event of the newest batch (submit_ms_last)
@@ -97,6 +100,11 @@ struct ppqc_ctx {
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
     hipEvent_t ev_max = nullptr;   // behind the extremes kernel: fork point of the sort chain when lens32 comes from it
+    // Largest read length of the run as the HOST knows it (number of radix passes without a device gate): from the
+    // offsets ppqc_submit validates anyway, or from len_bound_kernel run on the auxiliary stream at ppqc_submit_device.
+    uint64_t len_bound = 0;
+    bool bound_pending = false;                       // a len_bound_kernel's result has not been read yet
+    hipEvent_t ev_bound = nullptr;                    // behind the newest len_bound_kernel
     uint64_t* maxlen_host = nullptr;   // a few pinned scratch words (line count of the GPU tokenizer)
     ppqc_timing timing{};
 };
@@ -272,6 +280,7 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventCreate(&c->ev_t0)); HIPCHK(hipEventCreate(&c->ev_t1));
     HIPCHK(hipEventCreate(&c->ev_s0)); HIPCHK(hipEventCreate(&c->ev_s1));
     HIPCHK(hipEventCreateWithFlags(&c->ev_max, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_bound, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->ev_join));
     HIPCHK(hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
@@ -332,6 +341,7 @@ int ppqc_destroy(ppqc_ctx* c) {
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->maxlen_host) (void)hipHostFree(c->maxlen_host);
     if (c->ev_max) (void)hipEventDestroy(c->ev_max);
+    if (c->ev_bound) (void)hipEventDestroy(c->ev_bound);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_reads) (void)hipEventDestroy(c->ev_reads);
@@ -357,11 +367,17 @@ int ppqc_reset(ppqc_ctx* c) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(launch_reset_errors(c->res_buf + c->res_words, c->stream));
+    if (c->bound_pending) HIPCHK(hipEventSynchronize(c->ev_bound));   // its ticket words are cleared below
+    // one launch clears the results and the words behind them (input errors, length bound, sort gate); the finalize that
+    // follows finds the buffer clean and enqueues no clear of its own
+    HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, true, c->stream));
+    c->res_clean = true;
     c->n_reads = 0;
     c->state = 0;
     c->n50 = 0;
     c->lens_early = true;
+    c->len_bound = 0;
+    c->bound_pending = false;
     return PPQC_OK;
 }
 
@@ -425,6 +441,13 @@ int ppqc_submit_device(ppqc_ctx* c, const ppqc_batch* b) {
         return fail(PPQC_E_INVALID, "device bases/quals must be 16-byte aligned");
     HIPCHK(hipSetDevice(c->device));
     CHK(run_batch(c, b));
+    // The host learns the batch's largest read length while the tile kernel runs (see finalize_n50_impl).  Enqueued
+    // behind the batch's kernels in host order (every call in front of the tile kernel's launch delays its start) and
+    // ordered on the device behind the batch's start event, i.e. behind whatever produced the offsets on this stream.
+    HIPCHK(hipStreamWaitEvent(c->aux, c->last_a, 0));
+    HIPCHK(launch_len_bound(b->offsets, b->n_reads, c->res_buf + c->res_words + 4, c->maxlen_host + 4, c->aux));
+    HIPCHK(hipEventRecord(c->ev_bound, c->aux));
+    c->bound_pending = true;
     return PPQC_OK;
 }
 
@@ -436,9 +459,12 @@ int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
     if (R == 0) return PPQC_OK;
     // host-side validation of the CSR (the reference would fail inside the worker on a malformed read instead)
     if (b->offsets[0] != 0) return fail(PPQC_E_INVALID, "offsets[0] must be 0");
+    uint64_t longest = 0;
     for (uint64_t i = 0; i < R; ++i) {
         if (b->offsets[i + 1] < b->offsets[i]) return fail(PPQC_E_INVALID, "offsets not monotone");
-        if (b->offsets[i + 1] - b->offsets[i] >= 0xFFFFFFFFull) return fail(PPQC_E_RANGE, "read longer than 2^32-2");
+        const uint64_t l = b->offsets[i + 1] - b->offsets[i];
+        if (l >= 0xFFFFFFFFull) return fail(PPQC_E_RANGE, "read longer than 2^32-2");
+        longest = l > longest ? l : longest;
     }
     if (b->offsets[R] != b->n_bytes) return fail(PPQC_E_INVALID, "offsets[n_reads] != n_bytes");
     HIPCHK(hipSetDevice(c->device));
@@ -471,6 +497,7 @@ int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
     d.bases = s.bases; d.quals = s.quals; d.offsets = s.offsets; d.channel = s.channel; d.mux = s.mux;
     d.start_time_s = s.time; d.fail_flag = b->fail_flag ? s.ff : nullptr;
     CHK(run_batch(c, &d));
+    if (longest > c->len_bound) c->len_bound = longest;
     HIPCHK(hipEventRecord(s.done, c->stream));
     s.busy = true;
     return PPQC_OK;
@@ -662,16 +689,27 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     // The result buffer is cleared on the auxiliary stream: this call is usually enqueued while the per-read kernels of
     // the batch still run, and nothing before the extremes kernel touches the results, so the clear costs no time on
     // the main stream.  If an earlier finalize phase may still be running (no synchronisation since), it stays in line.
-    c->init_on_aux = !c->res_busy;
-    if (!c->res_busy) {
-        HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, c->aux));
-        HIPCHK(hipEventRecord(c->ev_init, c->aux));
-        HIPCHK(hipEventRecord(c->ev_t0, s));
-        HIPCHK(hipStreamWaitEvent(s, c->ev_init, 0));
+    // Straight after ppqc_reset the buffer is clean already (cleared on this stream before the batch): nothing is
+    // enqueued between finalize_reads and the extremes kernel, and ev_reads doubles as the start of the timings (every
+    // event record or wait on the stream costs about 6 us between two dependent kernels).
+    c->fin_start = c->ev_t0;
+    if (c->res_clean) {
+        c->init_on_aux = true;   // what it stands for holds: the clear precedes ev_reads
+        if (c->lens_early && c->n_reads) c->fin_start = c->ev_reads;
+        else HIPCHK(hipEventRecord(c->ev_t0, s));
     } else {
-        HIPCHK(hipEventRecord(c->ev_t0, s));
-        HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, s));
+        c->init_on_aux = !c->res_busy;
+        if (!c->res_busy) {
+            HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, false, c->aux));
+            HIPCHK(hipEventRecord(c->ev_init, c->aux));
+            HIPCHK(hipEventRecord(c->ev_t0, s));
+            HIPCHK(hipStreamWaitEvent(s, c->ev_init, 0));
+        } else {
+            HIPCHK(hipEventRecord(c->ev_t0, s));
+            HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, false, s));
+        }
     }
+    c->res_clean = false;
     HIPCHK(launch_extremes(c->ra, c->n_reads, c->tp, c->max_buf, c->min_buf, c->tminmax, !c->lens_early, s));
     if (!c->lens_early) HIPCHK(hipEventRecord(c->ev_max, s));   // fork point of the sort + N50 chain (ppqc_finalize_n50)
     c->state = 1;
@@ -746,28 +784,47 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     const int gate_words = early ? kGateWords : 1;
     CHK(ensure_sort32(c, n ? n : 1));
     if (ss != s) HIPCHK(hipStreamWaitEvent(ss, early ? c->ev_reads : c->ev_max, 0));
-    HIPCHK(hipEventRecord(c->ev_s0, ss));
-    HIPCHK(sort_u32_gated(dlens, c->sk32, c->sk32_tmp, n, c->counts, gate, gate_words, ss));
-    // ppqc_finalize: everything the host needs except the N50 is final once the tables kernel is done.  It is copied to
-    // the pinned mirror on the main stream now, beside the sort chain (1.6 MB at 512x4x48), and the N50 kernels write
-    // their result straight into the mirror, so ppqc_fetch_tables only has to wait for the join: no copy behind it.
+    c->sort_start = c->ev_s0;
+    if (ss != s && early && c->n_reads) c->sort_start = c->ev_reads;   // the chain starts right behind it
+    else HIPCHK(hipEventRecord(c->ev_s0, ss));
     // The N50 word of the mirror lies outside the copied range (the spare word behind the error words), so the copy,
     // which carries the device's not yet final n50_out along, cannot overwrite it.
     const bool early_out = early_fetch && c->state == 2 && ss != s;
-    HIPCHK(launch_n50_gated(dlens, c->sk32, c->sk32_tmp, gate, gate_words, n, c->n50_blocks, c->n50_out,
-                            early_out ? c->res_host + c->res_words + 3 : nullptr, ss));
+    uint64_t* host_out = early_out ? c->res_host + c->res_words + 3 : nullptr;
+    static const bool use_host_bound = !(getenv("PPQC_HOST_BOUND") && atoi(getenv("PPQC_HOST_BOUND")) == 0);   // A/B knob
+    if (early && use_host_bound) {
+        // Every read of the run came in as a CSR batch, so the host knows (or is about to know: the kernel was started
+        // when the batch was submitted and ran beside the tile kernel) the largest length: exactly the passes the keys
+        // need are enqueued, none that would only find out on the device that it has nothing to do.
+        if (c->bound_pending) {
+            HIPCHK(hipEventSynchronize(c->ev_bound));
+            if (c->maxlen_host[4] > c->len_bound) c->len_bound = c->maxlen_host[4];
+            c->bound_pending = false;
+        }
+        const uint64_t m = c->len_bound;
+        const uint32_t mask = m < (1ull << 8) ? 1u : (m < (1ull << 16) ? 3u : (m < (1ull << 24) ? 7u : 15u));
+        const uint32_t* sorted = dlens;
+        HIPCHK(sort_u32(dlens, c->sk32, c->sk32_tmp, n, c->counts, mask, ss, &sorted));
+        HIPCHK(launch_n50(sorted, n, c->n50_blocks, c->n50_out, host_out, ss));
+    } else {
+        HIPCHK(sort_u32_gated(dlens, c->sk32, c->sk32_tmp, n, c->counts, gate, gate_words, ss));
+        HIPCHK(launch_n50_gated(dlens, c->sk32, c->sk32_tmp, gate, gate_words, n, c->n50_blocks, c->n50_out, host_out, ss));
+    }
     c->sort_end = c->ev_s1;
     if (ss == s) HIPCHK(hipEventRecord(c->ev_s1, ss));
     if (ss != s) {
-        if (early_out) {
+        if (early_out) {   // ppqc_finalize: all but the N50 is final behind the tables kernel; copied beside the sort chain
             HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, (c->res_words + 3) * 8, hipMemcpyDeviceToHost, s));
             c->sum_fetched = true;
         }
         HIPCHK(hipEventRecord(c->ev_join, ss));   // also the end of the sort timing
         c->sort_end = c->ev_join;
+        HIPCHK(hipEventRecord(c->ev_t1, s));      // end of the main chain; the finalize ends at the later of the two
         HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+    } else {
+        HIPCHK(hipEventRecord(c->ev_t1, s));
     }
-    HIPCHK(hipEventRecord(c->ev_t1, s));
+    c->end_split = ss != s;
     c->state = 3;
     return mark_busy(c);
 }
@@ -810,8 +867,13 @@ static int fetch_tables_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
     o->lin_bin_width = mx[0] / PPQC_N_LEN_LIN + 1;
     o->n50 = c->n50 = n50_in_mirror ? h[c->res_words + 3] : (mn + 1 + nch)[2];
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1) == hipSuccess) c->timing.finalize_ms_last = ms;
-    if (hipEventElapsedTime(&ms, c->ev_s0, c->sort_end ? c->sort_end : c->ev_s1) == hipSuccess) c->timing.sort_ms_last = ms;
+    hipEvent_t f0 = c->fin_start ? c->fin_start : c->ev_t0, s0 = c->sort_start ? c->sort_start : c->ev_s0;
+    if (hipEventElapsedTime(&ms, f0, c->ev_t1) == hipSuccess) {
+        float ms2 = 0.f;
+        if (c->end_split && c->sort_end && hipEventElapsedTime(&ms2, f0, c->sort_end) == hipSuccess && ms2 > ms) ms = ms2;
+        c->timing.finalize_ms_last = ms;
+    }
+    if (hipEventElapsedTime(&ms, s0, c->sort_end ? c->sort_end : c->ev_s1) == hipSuccess) c->timing.sort_ms_last = ms;
     (void)hipGetLastError();   // an unrecorded event is not an error of the caller
     return PPQC_OK;
 }
@@ -855,7 +917,7 @@ int ppqc_n50_select_hist(ppqc_ctx* c, int round) {
     const bool side = round == 0 && c->lens_early && c->init_on_aux;   // the clear of sel_buf must precede on aux
     hipStream_t ss = side ? c->aux : c->stream;
     if (side) HIPCHK(hipStreamWaitEvent(ss, c->ev_reads, 0));
-    if (round == 0) HIPCHK(hipEventRecord(c->ev_s0, ss));
+    if (round == 0) { c->sort_start = c->ev_s0; HIPCHK(hipEventRecord(c->ev_s0, ss)); }
     HIPCHK(launch_select_hist(c->ra.lens32, c->n_reads, kSelShift[round], kSelBits[round], c->sel_state, c->sel_buf, ss));
     if (side) {
         HIPCHK(hipEventRecord(c->ev_join, ss));
@@ -875,6 +937,7 @@ int ppqc_n50_select_pick(ppqc_ctx* c, int round) {
         HIPCHK(hipEventRecord(c->ev_s1, c->stream));
         c->sort_end = c->ev_s1;
         HIPCHK(hipEventRecord(c->ev_t1, c->stream));
+        c->end_split = false;
         c->state = 3;
     }
     return mark_busy(c);

@@ -94,8 +94,8 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
 hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s);
 // res = [n_zero sums (tables + select histogram) = 0 | nch1 max = 0 | nch1 ~min = ~INT64_MAX | tmin = INT64_MAX,
 //        tmax = INT64_MIN | n50, total = 0 | 4 words of select state = 0]
-hipError_t launch_init_results(uint64_t* res, uint64_t n_zero, uint64_t nch1, hipStream_t s);
-hipError_t launch_reset_errors(uint64_t* e, hipStream_t s);
+hipError_t launch_init_results(uint64_t* res, uint64_t n_sum, uint64_t nch1, bool with_tail, hipStream_t s);
+hipError_t launch_len_bound(const uint64_t* offsets, uint64_t n, uint64_t* w, uint64_t* host_out, hipStream_t s);
 
 // time_mode 1 helpers
 hipError_t launch_mode1_keys(ReadArrays ra, uint64_t n, const TableParams& tp, const int64_t* tminmax, uint64_t* keys,
@@ -119,7 +119,8 @@ hipError_t sort_u64_pairs(uint64_t* keys, uint64_t* tmp_keys, uint32_t* vals, ui
 
 // N50 over ascending-sorted lengths: out[0] = n50, out[1] = total bases.  block_sums has n/2048 + 2 u64.
 uint64_t n50_block_words(uint64_t n);
-hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s);
+hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, uint64_t* host_out,
+                      hipStream_t s);
 // after sort_u32_gated(in, buf_a, buf_b, .., gate): picks the buffer the sorted keys ended in from the same gate word
 hipError_t launch_n50_gated(const uint32_t* in, const uint32_t* buf_a, const uint32_t* buf_b, const uint64_t* gate,
                             int gate_words, uint64_t n, uint64_t* block_sums, uint64_t* out, uint64_t* host_out,

@@ -343,8 +343,9 @@ static hipError_t n50_launch(const uint32_t* sa, const uint32_t* sb, const uint6
                        (uint32_t)nblocks, out, host_out);
     return hipGetLastError();
 }
-hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, hipStream_t s) {
-    return n50_launch(sorted, nullptr, nullptr, 1, sorted, n, block_sums, out, nullptr, s);
+hipError_t launch_n50(const uint32_t* sorted, uint64_t n, uint64_t* block_sums, uint64_t* out, uint64_t* host_out,
+                      hipStream_t s) {
+    return n50_launch(sorted, nullptr, nullptr, 1, sorted, n, block_sums, out, host_out, s);
 }
 hipError_t launch_n50_gated(const uint32_t* in, const uint32_t* buf_a, const uint32_t* buf_b, const uint64_t* gate,
                             int gate_words, uint64_t n, uint64_t* block_sums, uint64_t* out, uint64_t* host_out,

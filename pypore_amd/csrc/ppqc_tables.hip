@@ -303,29 +303,63 @@ hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const u
 
 // the four input-error words behind the results: [0] bad CSR rows, [1] bad FASTQ records, [2] first of them, [3] bad
 // quality bytes; [8 .. 8 + kGateWords) the sort gate (OR of the sort keys of the run, raised by finalize_reads)
-__global__ void reset_errors_kernel(uint64_t* e) {
-    if (threadIdx.x < 8 + kGateWords) e[threadIdx.x] = threadIdx.x == 2 ? ~0ull : 0ull;
+// Largest read length of a batch from its offsets, for the HOST: it runs on the auxiliary stream when the batch is
+// submitted (beside the tile kernel), so that by the time the sort is enqueued the host knows how many radix passes the
+// keys need.  w[0] run maximum (device, atomicMax), w[1] ticket counter; the block with the last ticket stores the run
+// maximum into the pinned host word.
+__global__ __launch_bounds__(256) void len_bound_kernel(const uint64_t* __restrict__ offsets, uint64_t n, uint64_t* w,
+                                                        uint64_t* __restrict__ host_out) {
+    __shared__ unsigned long long s_max;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    unsigned long long m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const unsigned long long l = offsets[i + 1] - offsets[i];
+        m = l > m ? l : m;
+    }
+    for (int o = 32; o; o >>= 1) { const unsigned long long v = __shfl_xor(m, o); m = v > m ? v : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax((unsigned long long*)&w[0], s_max);
+        __threadfence();
+        const unsigned long long ticket = atomicAdd((unsigned long long*)&w[1], 1ull);
+        if (ticket == gridDim.x - 1ull) {
+            __threadfence();
+            host_out[0] = __hip_atomic_load(&w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&w[1], (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
-hipError_t launch_reset_errors(uint64_t* e, hipStream_t s) {
-    hipLaunchKernelGGL(reset_errors_kernel, dim3(1), dim3(128), 0, s, e);
+
+hipError_t launch_len_bound(const uint64_t* offsets, uint64_t n, uint64_t* w, uint64_t* host_out, hipStream_t s) {
+    uint64_t blocks = (n + 2047) / 2048;
+    if (blocks > 128) blocks = 128;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(len_bound_kernel, dim3((unsigned)blocks), dim3(256), 0, s, offsets, n, w, host_out);
     return hipGetLastError();
 }
 
-__global__ void init_results_kernel(uint64_t* res, uint64_t n_sum, uint64_t nch1) {
+// `tail` > 0: the words behind the results (input errors, length bound and ticket, sort gate) are reset as well
+// (all zero but the number of the first bad FASTQ record): ppqc_reset clears everything with one launch.
+__global__ void init_results_kernel(uint64_t* res, uint64_t n_sum, uint64_t nch1, uint32_t tail) {
     const uint64_t total = n_sum + 2 * nch1 + 8;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + tail; i += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t v = 0;
         if (i >= n_sum + nch1 && i < n_sum + 2 * nch1) v = (uint64_t)INT64_MIN;          // min section: ~INT64_MAX
         else if (i == n_sum + 2 * nch1) v = (uint64_t)INT64_MAX;                         // tmin
         else if (i == n_sum + 2 * nch1 + 1) v = (uint64_t)INT64_MIN;                     // tmax
+        else if (i == total + 2) v = ~0ull;                                              // first bad FASTQ record: none
         res[i] = v;
     }
 }
-hipError_t launch_init_results(uint64_t* res, uint64_t n_sum, uint64_t nch1, hipStream_t s) {
-    const uint64_t total = n_sum + 2 * nch1 + 8;
+
+hipError_t launch_init_results(uint64_t* res, uint64_t n_sum, uint64_t nch1, bool with_tail, hipStream_t s) {
+    const uint64_t total = n_sum + 2 * nch1 + 8 + (with_tail ? 8 + kGateWords : 0);
     uint64_t blocks = (total + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(init_results_kernel, dim3((unsigned)blocks), dim3(256), 0, s, res, n_sum, nch1);
+    hipLaunchKernelGGL(init_results_kernel, dim3((unsigned)blocks), dim3(256), 0, s, res, n_sum, nch1,
+                       with_tail ? 8u + kGateWords : 0u);
     return hipGetLastError();
 }
 
