@@ -100,11 +100,13 @@ struct ppqc_ctx {
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
     hipEvent_t ev_max = nullptr;   // behind the extremes kernel: fork point of the sort chain when lens32 comes from it
-    // Largest read length of the run as the HOST knows it (number of radix passes without a device gate): from the
-    // offsets ppqc_submit validates anyway, or from len_bound_kernel run on the auxiliary stream at ppqc_submit_device.
-    uint64_t len_bound = 0;
-    bool bound_pending = false;                       // a len_bound_kernel's result has not been read yet
-    hipEvent_t ev_bound = nullptr;                    // behind the newest len_bound_kernel
+    // Index-only work of a batch (lengths, per-channel extremes, time range, hours, lens32) runs on the auxiliary stream
+    // when the batch is submitted, beside its tile kernel (extremes_kernel<true>), as long as the result buffer is as
+    // ppqc_reset left it and nothing the hours depend on changes: the finalize then needs no extremes kernel, and the
+    // sort + N50 chain, which needs only lens32, runs beside the tile kernel as well.
+    bool pre_ok = false;    // every batch since ppqc_reset went that way
+    bool pre_run = false;   // ... and the finalize in progress relies on it (set by ppqc_finalize_extremes)
+    hipEvent_t ev_pre = nullptr;   // behind the newest of those kernels (auxiliary stream)
     uint64_t* maxlen_host = nullptr;   // a few pinned scratch words (line count of the GPU tokenizer)
     ppqc_timing timing{};
 };
@@ -145,7 +147,7 @@ static int ensure_reads(ppqc_ctx* c, uint64_t need) {
     CHK(grow(&r.qsum, n, cap, s)); CHK(grow(&r.mean_q, n, cap, s));
     CHK(grow(&r.err_hi, n, cap, s)); CHK(grow(&r.err_lo, n, cap, s)); CHK(grow(&r.flags, n, cap, s));
     CHK(grow(&r.channel, n, cap, s)); CHK(grow(&r.mux, n, cap, s)); CHK(grow(&r.time, n, cap, s));
-    CHK(grow(&r.hour, 0, cap, s)); CHK(grow(&r.lens32, n, cap, s));   // lens32 is filled batch by batch
+    CHK(grow(&r.hour, n, cap, s)); CHK(grow(&r.lens32, n, cap, s));   // both are filled batch by batch
     c->cap_reads = cap;
     return PPQC_OK;
 }
@@ -280,7 +282,7 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventCreate(&c->ev_t0)); HIPCHK(hipEventCreate(&c->ev_t1));
     HIPCHK(hipEventCreate(&c->ev_s0)); HIPCHK(hipEventCreate(&c->ev_s1));
     HIPCHK(hipEventCreateWithFlags(&c->ev_max, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_bound, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->ev_join));
     HIPCHK(hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
@@ -324,6 +326,10 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     HIPCHK(hipMalloc((void**)&c->chan_start, (uint64_t)cfg->n_channels * 4 + 64));
     HIPCHK(hipMalloc((void**)&c->first_desc, (uint64_t)cfg->n_channels * 4 + 64));
     if (cfg->max_reads_hint) CHK(ensure_reads(c, cfg->max_reads_hint));
+    // a new context starts as ppqc_reset leaves one: results cleared, batches may leave their index-only results early
+    HIPCHK(launch_init_results(c->res_buf, tp.lay.n_sum + PPQC_N_SEL, nch1, true, c->stream));
+    c->res_clean = true;
+    c->pre_ok = true;
     *out = c;
     return PPQC_OK;
 }
@@ -341,7 +347,7 @@ int ppqc_destroy(ppqc_ctx* c) {
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->maxlen_host) (void)hipHostFree(c->maxlen_host);
     if (c->ev_max) (void)hipEventDestroy(c->ev_max);
-    if (c->ev_bound) (void)hipEventDestroy(c->ev_bound);
+    if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_reads) (void)hipEventDestroy(c->ev_reads);
@@ -367,7 +373,6 @@ int ppqc_reset(ppqc_ctx* c) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->bound_pending) HIPCHK(hipEventSynchronize(c->ev_bound));   // its ticket words are cleared below
     // one launch clears the results and the words behind them (input errors, length bound, sort gate); the finalize that
     // follows finds the buffer clean and enqueues no clear of its own
     HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, true, c->stream));
@@ -376,8 +381,8 @@ int ppqc_reset(ppqc_ctx* c) {
     c->state = 0;
     c->n50 = 0;
     c->lens_early = true;
-    c->len_bound = 0;
-    c->bound_pending = false;
+    c->pre_ok = true;
+    c->pre_run = false;
     return PPQC_OK;
 }
 
@@ -415,8 +420,22 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->n_cu, s));
     HIPCHK(hipEventRecord(ev.b, s));
     c->pending.push_back(ev);
+    static const bool pre_enabled = !(getenv("PPQC_PRE") && atoi(getenv("PPQC_PRE")) == 0);   // A/B knob
+    const bool pre = c->pre_ok && c->res_clean && c->cfg.time_mode == 0 && pre_enabled;
+    if (!pre) c->pre_ok = false;
     HIPCHK(launch_finalize_reads(v, c->ra, base, c->head, c->tail, c->tp.thr_fail, c->tp.fail_q,
-                                 c->res_buf + c->res_words, c->cfg.n_channels, c->res_buf + c->res_words + 8, s));
+                                 c->res_buf + c->res_words, c->cfg.n_channels, c->res_buf + c->res_words + 8, !pre, s));
+    if (pre) {
+        // Enqueued behind the batch's kernels in host order (every call in front of the tile kernel's launch delays its
+        // start) and ordered on the device behind the batch's start event, i.e. behind whatever produced the index on
+        // this stream.  The main stream takes the result in behind finalize_reads, so everything that synchronises with
+        // the main stream (ppqc_sync, the slots' reuse, a grow of the arrays) covers this kernel too.
+        HIPCHK(hipStreamWaitEvent(c->aux, ev.a, 0));
+        HIPCHK(launch_batch_extremes(v, base, c->ra, c->tp, c->max_buf, c->min_buf, c->tminmax,
+                                     c->res_buf + c->res_words + 4, c->maxlen_host + 4, c->aux));
+        HIPCHK(hipEventRecord(c->ev_pre, c->aux));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_pre, 0));
+    }
     HIPCHK(hipEventRecord(c->ev_reads, s));
     c->n_reads += R;
     c->state = 0;
@@ -441,13 +460,6 @@ int ppqc_submit_device(ppqc_ctx* c, const ppqc_batch* b) {
         return fail(PPQC_E_INVALID, "device bases/quals must be 16-byte aligned");
     HIPCHK(hipSetDevice(c->device));
     CHK(run_batch(c, b));
-    // The host learns the batch's largest read length while the tile kernel runs (see finalize_n50_impl).  Enqueued
-    // behind the batch's kernels in host order (every call in front of the tile kernel's launch delays its start) and
-    // ordered on the device behind the batch's start event, i.e. behind whatever produced the offsets on this stream.
-    HIPCHK(hipStreamWaitEvent(c->aux, c->last_a, 0));
-    HIPCHK(launch_len_bound(b->offsets, b->n_reads, c->res_buf + c->res_words + 4, c->maxlen_host + 4, c->aux));
-    HIPCHK(hipEventRecord(c->ev_bound, c->aux));
-    c->bound_pending = true;
     return PPQC_OK;
 }
 
@@ -459,12 +471,9 @@ int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
     if (R == 0) return PPQC_OK;
     // host-side validation of the CSR (the reference would fail inside the worker on a malformed read instead)
     if (b->offsets[0] != 0) return fail(PPQC_E_INVALID, "offsets[0] must be 0");
-    uint64_t longest = 0;
     for (uint64_t i = 0; i < R; ++i) {
         if (b->offsets[i + 1] < b->offsets[i]) return fail(PPQC_E_INVALID, "offsets not monotone");
-        const uint64_t l = b->offsets[i + 1] - b->offsets[i];
-        if (l >= 0xFFFFFFFFull) return fail(PPQC_E_RANGE, "read longer than 2^32-2");
-        longest = l > longest ? l : longest;
+        if (b->offsets[i + 1] - b->offsets[i] >= 0xFFFFFFFFull) return fail(PPQC_E_RANGE, "read longer than 2^32-2");
     }
     if (b->offsets[R] != b->n_bytes) return fail(PPQC_E_INVALID, "offsets[n_reads] != n_bytes");
     HIPCHK(hipSetDevice(c->device));
@@ -497,7 +506,6 @@ int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
     d.bases = s.bases; d.quals = s.quals; d.offsets = s.offsets; d.channel = s.channel; d.mux = s.mux;
     d.start_time_s = s.time; d.fail_flag = b->fail_flag ? s.ff : nullptr;
     CHK(run_batch(c, &d));
-    if (longest > c->len_bound) c->len_bound = longest;
     HIPCHK(hipEventRecord(s.done, c->stream));
     s.busy = true;
     return PPQC_OK;
@@ -546,6 +554,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     c->n_reads += R;
     c->state = 0;
     c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
+    c->pre_ok = false;
     if (n_records) *n_records = R;
     return PPQC_OK;
 }
@@ -609,6 +618,7 @@ int ppqc_submit_records(ppqc_ctx* c, const ppqc_records* r) {
     c->n_reads += n;
     c->state = 0;
     c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
+    c->pre_ok = false;
     return PPQC_OK;
 }
 
@@ -693,6 +703,14 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     // enqueued between finalize_reads and the extremes kernel, and ev_reads doubles as the start of the timings (every
     // event record or wait on the stream costs about 6 us between two dependent kernels).
     c->fin_start = c->ev_t0;
+    c->pre_run = c->res_clean && c->pre_ok && c->n_reads > 0;
+    if (c->pre_run) {   // every batch left its extremes, hours and lens32 when it was submitted: nothing to do here
+        c->init_on_aux = true;
+        c->fin_start = c->ev_reads;
+        c->res_clean = false;
+        c->state = 1;
+        return mark_busy(c);
+    }
     if (c->res_clean) {
         c->init_on_aux = true;   // what it stands for holds: the clear precedes ev_reads
         if (c->lens_early && c->n_reads) c->fin_start = c->ev_reads;
@@ -726,6 +744,7 @@ int ppqc_time_range(ppqc_ctx* c, int64_t* out2) {
 
 int ppqc_set_ref_time(ppqc_ctx* c, int64_t ref_time) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
+    if (c->n_reads && ref_time != c->tp.ref_time_s) c->pre_ok = false;   // hours of the submitted batches are stale
     c->cfg.ref_time_s = ref_time;
     c->tp.ref_time_s = ref_time;
     return PPQC_OK;
@@ -783,6 +802,11 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     const uint64_t* gate = early ? c->res_buf + c->res_words + 8 : c->max_buf;
     const int gate_words = early ? kGateWords : 1;
     CHK(ensure_sort32(c, n ? n : 1));
+    // pre: the host knows the largest key (the batch kernels leave it in a pinned word), so exactly the passes the keys
+    // need are enqueued.  lens32 has been there since the batches were submitted, but the chain still waits for the end
+    // of finalize_reads: run beside the tile kernel its ten launches cost that kernel more time (3 %: every wave
+    // resident beside it displaces one of its own) than they take behind it, beside the tables kernel.
+    const bool pre = local && c->pre_run && ss != s;
     if (ss != s) HIPCHK(hipStreamWaitEvent(ss, early ? c->ev_reads : c->ev_max, 0));
     c->sort_start = c->ev_s0;
     if (ss != s && early && c->n_reads) c->sort_start = c->ev_reads;   // the chain starts right behind it
@@ -791,17 +815,9 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     // which carries the device's not yet final n50_out along, cannot overwrite it.
     const bool early_out = early_fetch && c->state == 2 && ss != s;
     uint64_t* host_out = early_out ? c->res_host + c->res_words + 3 : nullptr;
-    static const bool use_host_bound = !(getenv("PPQC_HOST_BOUND") && atoi(getenv("PPQC_HOST_BOUND")) == 0);   // A/B knob
-    if (early && use_host_bound) {
-        // Every read of the run came in as a CSR batch, so the host knows (or is about to know: the kernel was started
-        // when the batch was submitted and ran beside the tile kernel) the largest length: exactly the passes the keys
-        // need are enqueued, none that would only find out on the device that it has nothing to do.
-        if (c->bound_pending) {
-            HIPCHK(hipEventSynchronize(c->ev_bound));
-            if (c->maxlen_host[4] > c->len_bound) c->len_bound = c->maxlen_host[4];
-            c->bound_pending = false;
-        }
-        const uint64_t m = c->len_bound;
+    if (pre) {
+        HIPCHK(hipEventSynchronize(c->ev_pre));   // a wait of the host while the GPU is busy with the tile kernel
+        const uint64_t m = c->maxlen_host[4];
         const uint32_t mask = m < (1ull << 8) ? 1u : (m < (1ull << 16) ? 3u : (m < (1ull << 24) ? 7u : 15u));
         const uint32_t* sorted = dlens;
         HIPCHK(sort_u32(dlens, c->sk32, c->sk32_tmp, n, c->counts, mask, ss, &sorted));

@@ -79,7 +79,7 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
                               Partial* head, Partial* tail, int n_cu, hipStream_t s, bool line_mode = false);
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint64_t thr_fail, double fail_q, uint64_t* csr_errors,
-                                 uint32_t n_channels, uint64_t* gate, hipStream_t s);
+                                 uint32_t n_channels, uint64_t* gate, bool write_lens, hipStream_t s);
 
 // Pre-computed reads (sequencing_summary.txt rows): device arrays of n entries appended at read_base.
 hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const uint32_t* len, const double* mean_q,
@@ -88,6 +88,9 @@ hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const u
 
 hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* max_buf, uint64_t* min_buf,
                            int64_t* tminmax, bool write_lens, hipStream_t s);
+hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays ra, const TableParams& tp,
+                                 uint64_t* max_buf, uint64_t* min_buf, int64_t* tminmax, uint64_t* bound,
+                                 uint64_t* bound_host, hipStream_t s);   // at submit time, beside the tile kernel
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
                          hipStream_t s);
 
@@ -95,7 +98,6 @@ hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s);
 // res = [n_zero sums (tables + select histogram) = 0 | nch1 max = 0 | nch1 ~min = ~INT64_MAX | tmin = INT64_MAX,
 //        tmax = INT64_MIN | n50, total = 0 | 4 words of select state = 0]
 hipError_t launch_init_results(uint64_t* res, uint64_t n_sum, uint64_t nch1, bool with_tail, hipStream_t s);
-hipError_t launch_len_bound(const uint64_t* offsets, uint64_t n, uint64_t* w, uint64_t* host_out, hipStream_t s);
 
 // time_mode 1 helpers
 hipError_t launch_mode1_keys(ReadArrays ra, uint64_t n, const TableParams& tp, const int64_t* tminmax, uint64_t* keys,

@@ -25,8 +25,17 @@ __device__ __forceinline__ int32_t hour_of_day(int64_t t, const TableParams& tp)
 // block; run extremes go through thread-local registers, one LDS atomic per thread, one global atomic per block.
 // min_buf holds the bitwise complement of each minimum (signed: ~L = -L-1, unseen = ~INT64_MAX = INT64_MIN), so that a
 // minimum is merged by MAX and [max_buf | min_buf] crosses xGMI in ONE all-reduce(MAX).
-__global__ __launch_bounds__(1024) void extremes_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* max_buf,
-                                                       uint64_t* min_buf, int64_t* tminmax, uint32_t nchL, int write_lens) {
+// BATCH = false: over the run's per-read arrays at finalize time (ppqc_finalize_extremes).
+// BATCH = true: over ONE batch's CSR index when the batch is submitted, on the auxiliary stream beside the tile kernel:
+// everything here depends on offsets, channel, start time and the fail flag only, none of it on the bases.  It
+// accumulates into the buffers ppqc_reset cleared, writes lens32 / hour of the batch's reads (run index base + i), and
+// the block that draws the last ticket (bound[1]) stores the run's largest key so far (max_buf[0]) into the pinned
+// host word: the host then knows how many radix passes the N50 sort needs.
+template <bool BATCH>
+__global__ __launch_bounds__(1024) void extremes_kernel(BatchView b, uint64_t base, ReadArrays ra, uint64_t n,
+                                                       TableParams tp, uint64_t* max_buf, uint64_t* min_buf,
+                                                       int64_t* tminmax, uint32_t nchL, int write_lens, uint64_t* bound,
+                                                       uint64_t* __restrict__ bound_host) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* s_cmax = reinterpret_cast<uint32_t*>(smem);
     uint32_t* s_cmin = s_cmax + nchL;
@@ -39,10 +48,25 @@ __global__ __launch_bounds__(1024) void extremes_kernel(ReadArrays ra, uint64_t 
     unsigned long long lmax = 0, lmin = (unsigned long long)INT64_MAX;
     long long tmin = INT64_MAX, tmax = INT64_MIN;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t ch = ra.channel[i];
+        uint32_t ch, L;
+        int64_t t;
+        uint64_t g = i;
+        if (BATCH) {
+            g = base + i;
+            ch = b.channel[i];
+            t = b.time[i];
+            // the length finalize_reads_kernel will store: 0 for a malformed row and for a read flagged as failed
+            uint64_t a = b.offsets[i], e = b.offsets[i + 1];
+            if (e < a || e > b.n_bytes || e - a >= 0xFFFFFFFFull || (i == 0 && a != 0) || (i + 1 == n && e != b.n_bytes))
+                a = e = 0;
+            L = (b.fail_flag != nullptr && b.fail_flag[i] != 0) ? 0u : (uint32_t)(e - a);
+        } else {
+            ch = ra.channel[i];
+            L = ra.len[i];
+            t = ra.time[i];
+        }
         const bool good = ch >= 1 && ch <= nch;
-        const uint32_t L = ra.len[i];
-        if (write_lens) ra.lens32[i] = good ? L : 0;   // else finalize_reads left it (and a sort may be reading it)
+        if (write_lens) ra.lens32[g] = good ? L : 0;   // else finalize_reads left it (and a sort may be reading it)
         int32_t hour = -1;
         if (good) {
             lmax = L > lmax ? L : lmax;
@@ -54,7 +78,6 @@ __global__ __launch_bounds__(1024) void extremes_kernel(ReadArrays ra, uint64_t 
                 atomicMax((unsigned long long*)&max_buf[ch], (unsigned long long)L);
                 atomicMax((long long*)&min_buf[ch], ~(long long)L);
             }
-            const int64_t t = ra.time[i];
             tmin = t < tmin ? t : tmin;
             tmax = t > tmax ? t : tmax;
             if (tp.time_mode == 0) {
@@ -62,7 +85,7 @@ __global__ __launch_bounds__(1024) void extremes_kernel(ReadArrays ra, uint64_t 
                 hour = (h >= 0 && h < (int64_t)tp.lay.n_time_bins) ? (int32_t)h : -1;
             }
         }
-        if (tp.time_mode == 0) ra.hour[i] = hour;
+        if (tp.time_mode == 0) ra.hour[g] = hour;
     }
     if (lmax) atomicMax(&s_max, lmax);
     if (lmin != (unsigned long long)INT64_MAX) atomicMin(&s_min, lmin);
@@ -79,6 +102,15 @@ __global__ __launch_bounds__(1024) void extremes_kernel(ReadArrays ra, uint64_t 
         atomicMax((long long*)&min_buf[0], ~(long long)s_min);
         atomicMin((long long*)&tminmax[0], s_tmin);
         atomicMax((long long*)&tminmax[1], s_tmax);
+        if (BATCH) {
+            __threadfence();
+            const unsigned long long ticket = atomicAdd((unsigned long long*)&bound[1], 1ull);
+            if (ticket == gridDim.x - 1ull) {
+                __threadfence();
+                bound_host[0] = __hip_atomic_load(&max_buf[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&bound[1], (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -303,43 +335,6 @@ hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const u
 
 // the four input-error words behind the results: [0] bad CSR rows, [1] bad FASTQ records, [2] first of them, [3] bad
 // quality bytes; [8 .. 8 + kGateWords) the sort gate (OR of the sort keys of the run, raised by finalize_reads)
-// Largest read length of a batch from its offsets, for the HOST: it runs on the auxiliary stream when the batch is
-// submitted (beside the tile kernel), so that by the time the sort is enqueued the host knows how many radix passes the
-// keys need.  w[0] run maximum (device, atomicMax), w[1] ticket counter; the block with the last ticket stores the run
-// maximum into the pinned host word.
-__global__ __launch_bounds__(256) void len_bound_kernel(const uint64_t* __restrict__ offsets, uint64_t n, uint64_t* w,
-                                                        uint64_t* __restrict__ host_out) {
-    __shared__ unsigned long long s_max;
-    if (threadIdx.x == 0) s_max = 0;
-    __syncthreads();
-    unsigned long long m = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-        const unsigned long long l = offsets[i + 1] - offsets[i];
-        m = l > m ? l : m;
-    }
-    for (int o = 32; o; o >>= 1) { const unsigned long long v = __shfl_xor(m, o); m = v > m ? v : m; }
-    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicMax((unsigned long long*)&w[0], s_max);
-        __threadfence();
-        const unsigned long long ticket = atomicAdd((unsigned long long*)&w[1], 1ull);
-        if (ticket == gridDim.x - 1ull) {
-            __threadfence();
-            host_out[0] = __hip_atomic_load(&w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&w[1], (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-hipError_t launch_len_bound(const uint64_t* offsets, uint64_t n, uint64_t* w, uint64_t* host_out, hipStream_t s) {
-    uint64_t blocks = (n + 2047) / 2048;
-    if (blocks > 128) blocks = 128;
-    if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(len_bound_kernel, dim3((unsigned)blocks), dim3(256), 0, s, offsets, n, w, host_out);
-    return hipGetLastError();
-}
-
 // `tail` > 0: the words behind the results (input errors, length bound and ticket, sort gate) are reset as well
 // (all zero but the number of the first bad FASTQ record): ppqc_reset clears everything with one launch.
 __global__ void init_results_kernel(uint64_t* res, uint64_t n_sum, uint64_t nch1, uint32_t tail) {
@@ -380,9 +375,25 @@ hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uin
     if (n == 0) return hipSuccess;
     // a length of 2^32-1 cannot be told from "unseen" in the u32 LDS copy: lengths are < 2^32-1 by the API contract
     const uint32_t nchL = tp.lay.n_channels <= 8192 ? tp.lay.n_channels : 0;
-    hipLaunchKernelGGL(extremes_kernel, dim3(grid_for(n, env_or("PPQC_EXT_BLOCKS", 256))),
-                       dim3(env_or("PPQC_EXT_THREADS", 512)), (size_t)nchL * 8, s, ra, n, tp, max_buf, min_buf, tminmax,
-                       nchL, write_lens ? 1 : 0);
+    hipLaunchKernelGGL(extremes_kernel<false>, dim3(grid_for(n, env_or("PPQC_EXT_BLOCKS", 256))),
+                       dim3(env_or("PPQC_EXT_THREADS", 512)), (size_t)nchL * 8, s, BatchView{}, (uint64_t)0, ra, n, tp,
+                       max_buf, min_buf, tminmax, nchL, write_lens ? 1 : 0, (uint64_t*)nullptr, (uint64_t*)nullptr);
+    return hipGetLastError();
+}
+
+// The same for one batch at submit time (see extremes_kernel<true>); bound[1] must be zero between launches.
+hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays ra, const TableParams& tp,
+                                 uint64_t* max_buf, uint64_t* min_buf, int64_t* tminmax, uint64_t* bound,
+                                 uint64_t* bound_host, hipStream_t s) {
+    if (b.n_reads == 0) return hipSuccess;
+    const uint32_t nchL = tp.lay.n_channels <= 8192 ? tp.lay.n_channels : 0;
+    // A small grid on purpose: the tile kernel fills every SIMD's registers (4 waves of 128), so each wave resident
+    // beside it displaces one of its waves for as long as it lives, and under a saturated HBM a latency-bound wave lives
+    // long.  64 x 256 threads finish well inside the tile kernel of any batch worth the trouble and cost it next to
+    // nothing (2048 waves of 8 reads each cost config 2 about 15 us of tile-kernel time).
+    hipLaunchKernelGGL(extremes_kernel<true>, dim3(grid_for(b.n_reads, env_or("PPQC_PRE_BLOCKS", 64))),
+                       dim3(env_or("PPQC_PRE_THREADS", 256)), (size_t)nchL * 8, s, b, base, ra, b.n_reads, tp, max_buf,
+                       min_buf, tminmax, nchL, 1, bound, bound_host);
     return hipGetLastError();
 }
 

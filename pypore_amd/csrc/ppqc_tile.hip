@@ -559,7 +559,8 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
                                                              const Partial* __restrict__ head,
                                                              const Partial* __restrict__ tail, uint64_t thr_fail,
                                                              double fail_q, uint64_t* __restrict__ csr_errors,
-                                                             uint32_t n_channels, uint64_t* __restrict__ gate) {
+                                                             uint32_t n_channels, uint64_t* __restrict__ gate,
+                                                             int write_lens) {
     __shared__ uint32_t s_max;
     if (threadIdx.x == 0) s_max = 0;
     __syncthreads();
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
         }
         const uint32_t ch = b.channel[i];
         const uint32_t key = (ch >= 1 && ch <= n_channels) ? len_out : 0u;   // what extremes_kernel would write
-        ra.lens32[g] = key;
+        if (write_lens) ra.lens32[g] = key;   // else the batch's extremes kernel wrote it at submit time
         if (key) atomicMax(&s_max, key);
         ra.mean_q[g] = mq;
         ra.flags[g] = flags;
@@ -676,11 +677,11 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
 
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint64_t thr_fail, double fail_q, uint64_t* csr_errors,
-                                 uint32_t n_channels, uint64_t* gate, hipStream_t s) {
+                                 uint32_t n_channels, uint64_t* gate, bool write_lens, hipStream_t s) {
     if (b.n_reads == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((b.n_reads + 255) / 256);
     hipLaunchKernelGGL(finalize_reads_kernel, dim3(blocks), dim3(256), 0, s, b, ra, read_base, head, tail, thr_fail,
-                       fail_q, csr_errors, n_channels, gate);
+                       fail_q, csr_errors, n_channels, gate, write_lens ? 1 : 0);
     return hipGetLastError();
 }
 
