@@ -233,7 +233,13 @@ int ppqc_read_hours(ppqc_ctx* ctx, int32_t* out, uint64_t first, uint64_t n);
  *   ppqc_finalize_tables   -> [all-reduce SUM sum_buf]
  *   ppqc_finalize_n50(ctx, NULL, 0) or, multi-GPU, with the all-gathered device array of lengths
  *   ppqc_fetch_tables
- * ppqc_finalize runs all four for the single-GPU case. */
+ * ppqc_finalize runs all four for the single-GPU case.
+ * On a context fresh from ppqc_create or ppqc_reset in time_mode 0, ppqc_submit / ppqc_submit_device also start, on the
+ * context's auxiliary stream, the part of ppqc_finalize_extremes that needs the CSR index only (lengths, per-channel
+ * extremes, time range, hour bins) beside the batch's per-read kernel; ppqc_finalize_extremes then enqueues nothing,
+ * and ppqc_finalize_n50 waits on the HOST for the batches' index kernels (microseconds, while the per-read kernel
+ * runs) to learn how many radix passes the lengths need.  Records / FASTQ-text input, a reference time set after the
+ * batches, a second finalize of one run and time_mode 1 take the finalize-time kernels; the results are the same. */
 int ppqc_finalize_extremes(ppqc_ctx* ctx);
 /* Smallest and largest start time over the reads with a valid channel (INT64_MAX / INT64_MIN if there is none); valid
  * after ppqc_finalize_extremes.  With ppqc_set_ref_time it gives RefTime = the earliest start when the caller has no

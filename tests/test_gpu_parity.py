@@ -96,6 +96,55 @@ def test_streamed_batches_equal_single_batch(qc, c_oracle):
     assert np.array_equal(h1, h2)
 
 
+def test_batch_time_extremes_equal_finalize_time_extremes(qc, c_oracle):
+    """A batch leaves its index-only results (extremes, hours, sort keys) when it is submitted, beside the tile kernel;
+    the same tables must come out when that is not possible: reference time set after the batches (hours stale),
+    a second finalize of the same run, batches added behind a finalize, and a reference time that moves reads out of
+    the binned range.  All against the oracle."""
+    b = random_batch(77, 6000, 800)
+    b["channel"][::97] = 0            # invalid channels: no sort key, no extremes, hour -1
+    b["fail_flag"][::13] = 1          # flagged reads count with length 0
+    ff = b["fail_flag"]
+    want = c_oracle.per_read(b["bases"], b["quals"], b["offsets"], nthreads=4)
+
+    def submit(ctx, a, e, slot=0):
+        o = b["offsets"][a:e + 1]
+        s0, s1 = int(o[0]), int(o[-1])
+        ctx.submit(b["bases"][s0:s1], b["quals"][s0:s1], o - o[0], b["channel"][a:e], b["mux"][a:e], b["time"][a:e],
+                   ff[a:e], slot=slot)
+
+    R = len(b["channel"])
+    for ref in (BASE_CFG["ref_time_s"], BASE_CFG["ref_time_s"] + 5 * 3600):
+        cfg = dict(BASE_CFG, ref_time_s=ref)
+        wt = c_oracle.tables(want, b["channel"], b["mux"], b["time"], ff, cfg)
+        # (a) the early path as it is
+        with qc.QCContext(device=0, **cfg) as ctx:
+            submit(ctx, 0, R)
+            t_pre = ctx.finalize()
+            h_pre = ctx.read_hours()
+            assert_tables_equal(t_pre, wt, "early")
+            # (b) a second finalize of the same run goes through the finalize-time kernels
+            assert_tables_equal(ctx.finalize(), wt, "second finalize")
+            assert np.array_equal(ctx.read_hours(), h_pre)
+        # (c) the reference time arrives after the batches
+        with qc.QCContext(device=0, **dict(cfg, ref_time_s=ref - 7 * 3600)) as ctx:
+            submit(ctx, 0, R // 2, 0)
+            submit(ctx, R // 2, R, 1)
+            ctx.set_ref_time(ref)
+            assert_tables_equal(ctx.finalize(), wt, "late reference time")
+            assert np.array_equal(ctx.read_hours(), h_pre)
+        # (d) batches behind a finalize, and a fresh run on the same context behind ppqc_reset
+        with qc.QCContext(device=0, **cfg) as ctx:
+            submit(ctx, 0, R // 3, 0)
+            ctx.finalize()
+            submit(ctx, R // 3, R, 1)
+            assert_tables_equal(ctx.finalize(), wt, "batches behind a finalize")
+            ctx.reset()
+            submit(ctx, 0, R // 2, 0)
+            submit(ctx, R // 2, R, 1)
+            assert_tables_equal(ctx.finalize(copy=False), wt, "behind reset")
+
+
 def test_no_fail_flag_and_all_flagged(qc, c_oracle):
     b = random_batch(41, 800, 500)
     _run(qc, b, BASE_CFG, c_oracle, use_ff=False)
