@@ -269,6 +269,22 @@ int ppqc_device_tables_view(ppqc_ctx* ctx, ppqc_device_tables* out);
 int ppqc_n50_select_hist(ppqc_ctx* ctx, int round);
 int ppqc_n50_select_pick(ppqc_ctx* ctx, int round);
 
+/* No counterpart in the reference (it has one process per channel and no N50).  Multi-GPU callers whose batches left
+ * their index-only results at submit time (see ppqc_finalize_extremes; ppqc_index_early says so) can merge everything
+ * that does not depend on the bases WHILE the per-read kernel runs, on a stream of their own:
+ *   ppqc_stream_wait_index(ctx, side)                     side waits for the batches' index kernels
+ *   all-reduce MAX of [max_buf | min_buf] on side
+ *   for round 0, 1, 2: ppqc_n50_select_early(ctx, round, 0, side); all-reduce SUM of sel_buf on side;
+ *                      ppqc_n50_select_early(ctx, round, 1, side)     (the total weight is taken from round 0's merged
+ *                                                                      histogram, not from the tables)
+ *   the context's stream waits for side; ppqc_finalize_extremes; ppqc_finalize_tables; all-reduce SUM of sum_buf;
+ *   ppqc_fetch_tables
+ * which leaves ONE collective behind the per-read kernel instead of four.  PPQC_E_STATE if the run does not qualify
+ * (then use the phases above). */
+int ppqc_index_early(ppqc_ctx* ctx, int* out);
+int ppqc_stream_wait_index(ppqc_ctx* ctx, void* stream);
+int ppqc_n50_select_early(ppqc_ctx* ctx, int round, int phase, void* stream);
+
 /* Enqueue all further work of the context on a caller-owned HIP stream (use_external != 0; `stream` is a hipStream_t,
  * 0 = the null stream) so that it is stream-ordered with the caller's own kernels and RCCL collectives without host
  * synchronisation, or go back to the context's own stream (use_external == 0).  Drains the previous stream first. */

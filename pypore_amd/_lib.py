@@ -29,7 +29,7 @@ SYMBOLS = (
     "ppqc_sync", "ppqc_n_reads", "ppqc_read_stats", "ppqc_read_hours", "ppqc_finalize_extremes",
     "ppqc_finalize_tables", "ppqc_finalize_n50", "ppqc_fetch_tables", "ppqc_fetch_tables_view", "ppqc_finalize", "ppqc_finalize_view", "ppqc_device_tables_view",
     "ppqc_timings", "ppqc_reset_timings", "ppqc_sort_u32_device", "ppqc_synth_fill_device", "ppqc_fastq_scan", "ppqc_fastq_pack",
-    "ppqc_submit_fastq", "ppqc_submit_fastq_device", "ppqc_input_errors", "ppqc_time_range", "ppqc_set_ref_time", "ppqc_n50_select_hist", "ppqc_n50_select_pick", "ppqc_set_stream",
+    "ppqc_submit_fastq", "ppqc_submit_fastq_device", "ppqc_input_errors", "ppqc_time_range", "ppqc_set_ref_time", "ppqc_n50_select_hist", "ppqc_n50_select_pick", "ppqc_index_early", "ppqc_stream_wait_index", "ppqc_n50_select_early", "ppqc_set_stream",
 )
 
 
@@ -138,6 +138,8 @@ def load():
         "ppqc_input_errors": [P, P], "ppqc_time_range": [P, P], "ppqc_set_ref_time": [P, C.c_int64],
         "ppqc_submit_fastq_device": [P, P, C.c_uint64, C.c_uint8, C.POINTER(C.c_uint64)],
         "ppqc_n50_select_hist": [P, C.c_int], "ppqc_n50_select_pick": [P, C.c_int],
+        "ppqc_index_early": [P, C.POINTER(C.c_int)], "ppqc_stream_wait_index": [P, C.c_void_p],
+        "ppqc_n50_select_early": [P, C.c_int, C.c_int, C.c_void_p],
         "ppqc_set_stream": [P, P, C.c_int],
         "ppqc_fastq_scan": [P, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "ppqc_fastq_pack": [P, C.c_uint64, C.c_uint64, P, P, P, P, P, P, P, C.POINTER(C.c_uint64)],

@@ -106,7 +106,9 @@ struct ppqc_ctx {
     // sort + N50 chain, which needs only lens32, runs beside the tile kernel as well.
     bool pre_ok = false;    // every batch since ppqc_reset went that way
     bool pre_run = false;   // ... and the finalize in progress relies on it (set by ppqc_finalize_extremes)
+    bool n50_early = false; // ppqc_n50_select_early has left the N50 of the run's reads (no batch since)
     hipEvent_t ev_pre = nullptr;   // behind the newest of those kernels (auxiliary stream)
+    hipEvent_t ev_clean = nullptr; // behind the clear of the result buffer (ppqc_reset / ppqc_create, main stream)
     uint64_t* maxlen_host = nullptr;   // a few pinned scratch words (line count of the GPU tokenizer)
     ppqc_timing timing{};
 };
@@ -283,6 +285,7 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventCreate(&c->ev_s0)); HIPCHK(hipEventCreate(&c->ev_s1));
     HIPCHK(hipEventCreateWithFlags(&c->ev_max, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_clean, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->ev_join));
     HIPCHK(hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
@@ -328,6 +331,7 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     if (cfg->max_reads_hint) CHK(ensure_reads(c, cfg->max_reads_hint));
     // a new context starts as ppqc_reset leaves one: results cleared, batches may leave their index-only results early
     HIPCHK(launch_init_results(c->res_buf, tp.lay.n_sum + PPQC_N_SEL, nch1, true, c->stream));
+    HIPCHK(hipEventRecord(c->ev_clean, c->stream));
     c->res_clean = true;
     c->pre_ok = true;
     *out = c;
@@ -348,6 +352,7 @@ int ppqc_destroy(ppqc_ctx* c) {
     if (c->maxlen_host) (void)hipHostFree(c->maxlen_host);
     if (c->ev_max) (void)hipEventDestroy(c->ev_max);
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
+    if (c->ev_clean) (void)hipEventDestroy(c->ev_clean);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_reads) (void)hipEventDestroy(c->ev_reads);
@@ -376,6 +381,7 @@ int ppqc_reset(ppqc_ctx* c) {
     // one launch clears the results and the words behind them (input errors, length bound, sort gate); the finalize that
     // follows finds the buffer clean and enqueues no clear of its own
     HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, true, c->stream));
+    HIPCHK(hipEventRecord(c->ev_clean, c->stream));
     c->res_clean = true;
     c->n_reads = 0;
     c->state = 0;
@@ -383,6 +389,7 @@ int ppqc_reset(ppqc_ctx* c) {
     c->lens_early = true;
     c->pre_ok = true;
     c->pre_run = false;
+    c->n50_early = false;
     return PPQC_OK;
 }
 
@@ -439,6 +446,7 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     HIPCHK(hipEventRecord(c->ev_reads, s));
     c->n_reads += R;
     c->state = 0;
+    c->n50_early = false;
     return PPQC_OK;
 }
 
@@ -780,6 +788,12 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
     }
     HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, c->max_buf, s));
     c->state = 2;
+    if (c->n50_early) {   // the N50 is there already (ppqc_n50_select_early): the finalize ends here
+        HIPCHK(hipEventRecord(c->ev_t1, s));
+        c->end_split = false;
+        c->sort_start = c->sort_end = nullptr;
+        c->state = 3;
+    }
     return mark_busy(c);
 }
 
@@ -948,13 +962,47 @@ int ppqc_n50_select_pick(ppqc_ctx* c, int round) {
     if (c->state < 2) return fail(PPQC_E_STATE, "call ppqc_finalize_tables first (the pick needs the merged total)");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(launch_select_pick(c->sel_buf, c->sum_buf + c->tp.lay.off_totals + PPQC_TOT_N_BASES, c->sel_state,
-                              kSelShift[round], kSelBits[round], round == 2, c->n50_out, c->stream));
+                              kSelShift[round], kSelBits[round], round == 2, false, c->n50_out, c->stream));
     if (round == 2) {
         HIPCHK(hipEventRecord(c->ev_s1, c->stream));
         c->sort_end = c->ev_s1;
         HIPCHK(hipEventRecord(c->ev_t1, c->stream));
         c->end_split = false;
         c->state = 3;
+    }
+    return mark_busy(c);
+}
+
+int ppqc_index_early(ppqc_ctx* c, int* out) {
+    if (!c || !out) return fail(PPQC_E_INVALID, "null argument");
+    *out = (c->pre_ok && c->res_clean && c->cfg.time_mode == 0) ? 1 : 0;   // also with no reads yet: an empty shard
+                                                                          // has to take the same path as its peers
+    return PPQC_OK;
+}
+
+int ppqc_stream_wait_index(ppqc_ctx* c, void* stream) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    if (!(c->pre_ok && c->res_clean && c->cfg.time_mode == 0))
+        return fail(PPQC_E_STATE, "the run's batches did not leave their index-only results at submit time");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_clean, 0));   // the clear of the result buffer (an empty run)
+    if (c->n_reads) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_pre, 0));
+    return PPQC_OK;
+}
+
+int ppqc_n50_select_early(ppqc_ctx* c, int round, int phase, void* stream) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    if (round < 0 || round > 2 || phase < 0 || phase > 1) return fail(PPQC_E_INVALID, "round must be 0..2, phase 0 or 1");
+    if (!(c->pre_ok && c->res_clean && c->cfg.time_mode == 0))
+        return fail(PPQC_E_STATE, "the run's batches did not leave their index-only results at submit time");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t ss = (hipStream_t)stream;
+    if (phase == 0) {
+        HIPCHK(launch_select_hist(c->ra.lens32, c->n_reads, kSelShift[round], kSelBits[round], c->sel_state, c->sel_buf, ss));
+    } else {
+        HIPCHK(launch_select_pick(c->sel_buf, nullptr, c->sel_state, kSelShift[round], kSelBits[round], round == 2,
+                                  round == 0, c->n50_out, ss));
+        if (round == 2) c->n50_early = true;
     }
     return mark_busy(c);
 }

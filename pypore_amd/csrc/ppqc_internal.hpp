@@ -134,7 +134,7 @@ hipError_t launch_n50_gated(const uint32_t* in, const uint32_t* buf_a, const uin
 hipError_t launch_select_hist(const uint32_t* lens, uint64_t n, int shift, int nbits, const uint64_t* state,
                               uint64_t* sel, hipStream_t s);
 hipError_t launch_select_pick(uint64_t* sel, const uint64_t* total, uint64_t* state, int shift, int nbits, bool last,
-                              uint64_t* out, hipStream_t s);
+                              bool first, uint64_t* out, hipStream_t s);   // total == nullptr: from the first round's histogram
 
 // ---- FASTQ text on the GPU (ppqc_fastq_gpu.hip) --------------------------------------------------------------------
 constexpr uint32_t kNlChunk = 4096;   // bytes of text per newline-count entry (one wave, four 1 KiB spans)

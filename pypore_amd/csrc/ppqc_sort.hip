@@ -385,13 +385,17 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const uint32_t* __rest
 
 // One block.  pred(d) = 2 * (above + sum_{d' >= d} sel[d']) >= total is monotone; the chosen digit is the largest d
 // with pred(d): the weight of strictly longer keys stays below half the total, with digit d included it reaches it.
+// `total` == nullptr: the total weight is the sum of the round's histogram when no bits are chosen yet (`first`: every
+// positive length falls into some digit of the top round), kept in state[2] for the later rounds.  That makes the
+// whole select independent of the tables, so it can run as soon as the lengths are known.
 __global__ __launch_bounds__(256) void select_pick_kernel(uint64_t* __restrict__ sel, const uint64_t* __restrict__ total,
                                                           uint64_t* __restrict__ state, int shift, int nbits, int last,
-                                                          uint64_t* __restrict__ out) {
+                                                          int first, uint64_t* __restrict__ out) {
     __shared__ uint64_t part[256];
+    __shared__ uint64_t s_T;
     const uint32_t t = threadIdx.x;
     const int per = (1 << nbits) / 256;   // 8 or 4 digits per thread
-    const uint64_t T = total[0], prefix = state[0], above = state[1];
+    const uint64_t prefix = state[0], above = state[1];
     uint64_t w[8], loc = 0;
     for (int k = 0; k < per; ++k) { w[k] = sel[t * per + k]; loc += w[k]; }
     part[t] = loc;
@@ -399,8 +403,14 @@ __global__ __launch_bounds__(256) void select_pick_kernel(uint64_t* __restrict__
     if (t == 0) {
         uint64_t run = 0;
         for (int i = 255; i >= 0; --i) { const uint64_t x = part[i]; part[i] = run; run += x; }
+        uint64_t T;
+        if (total) T = total[0];
+        else if (first) { T = run; state[2] = run; }
+        else T = state[2];
+        s_T = T;
     }
     __syncthreads();
+    const uint64_t T = s_T;
     uint64_t after = above + part[t];
     for (int k = per - 1; k >= 0; --k) {
         const uint64_t suf = after + w[k];
@@ -429,8 +439,9 @@ hipError_t launch_select_hist(const uint32_t* lens, uint64_t n, int shift, int n
 }
 
 hipError_t launch_select_pick(uint64_t* sel, const uint64_t* total, uint64_t* state, int shift, int nbits, bool last,
-                              uint64_t* out, hipStream_t s) {
-    hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, s, sel, total, state, shift, nbits, last ? 1 : 0, out);
+                              bool first, uint64_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, s, sel, total, state, shift, nbits, last ? 1 : 0,
+                       first ? 1 : 0, out);
     return hipGetLastError();
 }
 

@@ -38,7 +38,18 @@ def gather_lengths(lengths_t, dist, torch, group=None):
     return out
 
 
-def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True):
+_SIDE = {}
+
+
+def _side_stream(torch):
+    """One extra stream per device for the merges that run beside the per-read kernel."""
+    dev = torch.cuda.current_device()
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE[dev]
+
+
+def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, early=None):
     """Phased finalize of a QCContext with RCCL merges in between; returns the merged tables on every rank.
 
     The context is put on torch's current stream, so its kernels and the collectives (which torch orders against that
@@ -48,10 +59,35 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True):
     all-reduced (the first one rides along with the table buffer), so only small tables cross xGMI and the cost does
     not grow with the number of ranks.  ``n50="gather"``: all-gather the u32 lengths and run the LSD radix sort + N50
     on every rank (the single-GPU algorithm; its sort grows with the whole job).  ``copy=False``: the tables are views
-    of the context's pinned result buffer (``QCContext.fetch_tables``)."""
+    of the context's pinned result buffer (``QCContext.fetch_tables``).
+
+    ``early`` (default: whenever the context says it can, ``QCContext.index_early`` -- every rank must take the same
+    path, and does when all ranks drive their contexts through the same calls): the extremes all-reduce and the three
+    select rounds depend on the CSR index only, which the batches left when they were submitted; they are issued on a
+    side stream and run WHILE the per-read kernel does, so that one collective (the table SUM) is left behind it."""
     handle = torch.cuda.current_stream().cuda_stream
     if ctx.external_stream != handle:
         ctx.set_stream(handle)
+    if early is None:
+        early = n50 == "select" and ctx.index_early()
+    if early:
+        side = _side_stream(torch)
+        ctx.stream_wait_index(side.cuda_stream)
+        views, _ = ctx.device_tables()
+        with torch.cuda.stream(side):
+            t_maxmin = torch.as_tensor(views["maxmin"], device="cuda")
+            dist.all_reduce(t_maxmin, op=dist.ReduceOp.MAX, group=group)
+            t_sel = torch.as_tensor(views["sel"], device="cuda")
+            for r in range(3):
+                ctx.n50_select_early(r, 0, side.cuda_stream)
+                dist.all_reduce(t_sel, op=dist.ReduceOp.SUM, group=group)
+                ctx.n50_select_early(r, 1, side.cuda_stream)
+        torch.cuda.current_stream().wait_stream(side)
+        ctx.finalize_extremes()
+        ctx.finalize_tables()                    # uses the merged max_len; the N50 is final already
+        t_sum = torch.as_tensor(views["sum"], device="cuda")
+        dist.all_reduce(t_sum, op=dist.ReduceOp.SUM, group=group)
+        return ctx.fetch_tables(copy=copy)
     ctx.finalize_extremes()
     views, _ = ctx.device_tables()
     # the device keeps the minima complemented, so maxima and minima merge in ONE all-reduce(MAX)

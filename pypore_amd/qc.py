@@ -248,6 +248,19 @@ class QCContext:
     def n50_select_pick(self, rnd):
         L.check(self._lib.ppqc_n50_select_pick(self._ctx, int(rnd)))
 
+    def index_early(self):
+        """True if every batch of the run left its index-only results (extremes, hours, sort keys) at submit time."""
+        out = C.c_int(0)
+        L.check(self._lib.ppqc_index_early(self._ctx, C.byref(out)))
+        return bool(out.value)
+
+    def stream_wait_index(self, stream_handle):
+        L.check(self._lib.ppqc_stream_wait_index(self._ctx, C.c_void_p(int(stream_handle))))
+
+    def n50_select_early(self, rnd, phase, stream_handle):
+        """Histogram (phase 0) / pick (phase 1) of select round ``rnd`` on a caller's stream, independent of the tables."""
+        L.check(self._lib.ppqc_n50_select_early(self._ctx, int(rnd), int(phase), C.c_void_p(int(stream_handle))))
+
     def n50_select(self):
         """Single-GPU run of the multi-GPU N50 path (three histogram / pick rounds, no collectives in between)."""
         for r in range(3):

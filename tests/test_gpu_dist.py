@@ -1,6 +1,7 @@
 """The RCCL merge path of bench.py --gpus N, exercised on the one GPU a test box has: a 1-rank "nccl" group runs
-finalize_distributed (all-reduce MAX/MIN, all-reduce SUM on the fused table buffer, all-gather of the lengths, N50
-over the gathered lengths) directly on the library's device buffers.  The N-rank arithmetic is covered by the 2-rank
+finalize_distributed directly on the library's device buffers: the early merge (extremes all-reduce and the three
+select rounds on a side stream beside the per-read kernel, one table SUM behind it), the phased merge (four collectives
+behind the kernel) and the gather variant (all-gather of the lengths, sort on every rank).  The N-rank arithmetic is covered by the 2-rank
 gloo test (tests/test_dist_gloo.py)."""
 import socket
 
@@ -32,6 +33,15 @@ def test_finalize_distributed_one_rank_nccl_and_zero_copy_views(c_oracle):
             ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], b["fail_flag"])
             merged = finalize_distributed(ctx, dist, torch)                  # N50 by radix select (default)
             assert ctx.external_stream == torch.cuda.current_stream().cuda_stream
+            assert ctx.index_early() is False                                # consumed by the finalize
+            ctx.reset()
+            ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], b["fail_flag"])
+            assert ctx.index_early() is True
+            phased = finalize_distributed(ctx, dist, torch, early=False)     # four collectives behind the kernel
+            assert_tables_equal(merged, phased, "early vs phased merge")
+            ctx.reset()                                                      # an empty shard takes the early path too
+            empty = finalize_distributed(ctx, dist, torch)
+            assert empty["totals"].sum() == 0 and empty["n50"] == 0 and empty["max_len"] == 0
             ctx.reset()
             ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], b["fail_flag"])
             gathered = finalize_distributed(ctx, dist, torch, n50="gather")   # all-gather + sort on every rank
