@@ -6,12 +6,17 @@ collective; only the small integer tables are merged -- the counterpart of gathe
 the multiprocessing result queue in the reference (lib/seq_routines.py:940-942) and of the sum over channels in
 FastStats (lib/seq_routines.py:103-108):
 
+  beside the per-read kernel, on a side stream (everything here needs the CSR index only, which the batches left when
+  they were submitted):
   1. one all-reduce MAX on [max_len | chan_max_len | ~min_pos_len | ~chan_min_len] (a few KB; the device keeps the
      minima bitwise complemented so that they merge by MAX too)
-  2. all-reduce SUM on the fused u64 table buffer (1.6 MB at 512x4x48, 13.9 MB at 3000x4x72) -- one call; at these
+  2. exact N50 by weighted radix select: three 2048-word histograms, each all-reduced between its histogram and its
+     pick (the alternative n50="gather" all-gathers the u32 lengths and sorts them on every rank)
+  behind it:
+  3. all-reduce SUM on the fused u64 table buffer (1.6 MB at 512x4x48, 13.9 MB at 3000x4x72) -- one call; at these
      sizes the ring is latency-bound on xGMI, so it is not bucketed or pipelined
-  3. exact N50 by weighted radix select: three 2048-word histograms all-reduced (the first fused into step 2); the
-     alternative (n50="gather") all-gathers the u32 lengths and sorts them on every rank
+  (early=False, or a context that cannot tell its index-only results early: the same merges as four collectives behind
+  the kernel, the first select histogram fused into the table buffer's all-reduce)
 
 time_mode 1 (the reference's per-channel hour-wrap quirk) needs all reads of a channel on one rank: shard by channel.
 """
