@@ -61,3 +61,22 @@ def test_finalize_distributed_one_rank_nccl_and_zero_copy_views(c_oracle):
         assert_tables_equal(merged, c_oracle.tables(want, b["channel"], b["mux"], b["time"], b["fail_flag"], cfg))
     finally:
         dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_over_gloo():
+    """tools/dist_rehearsal.py: world_size 2 (two processes sharing the one GPU, gloo because RCCL refuses two ranks on a
+    device): early, phased and gather merge and an empty shard on one rank, every rank's tables against the host merge
+    of the single-shard tables and the oracle's N50 over all lengths."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "tools", "dist_rehearsal.py")],
+                       capture_output=True, text=True, timeout=170, cwd=root)
+    assert r.returncode == 0 and "dist rehearsal ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
