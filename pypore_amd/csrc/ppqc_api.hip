@@ -804,12 +804,12 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     hipStream_t s = c->stream;
     if (!dlens) { dlens = c->ra.lens32; n = c->n_reads; }
     if (n >= (1ull << 32)) return fail(PPQC_E_RANGE, "more than 2^32-1 lengths");
-    // The sort passes are gated on the device by a word that bounds every key (no host round trip).  Local lengths: the
-    // chain runs on the auxiliary stream beside the extremes and tables kernels.  When every read of the run came through
-    // finalize_reads, lens32 and the gate (largest key) are complete behind the last of those kernels (ev_reads);
-    // otherwise the extremes kernel writes lens32 and max_buf[0] is the gate (fork at ev_max).  Gathered lengths of
-    // other ranks are bounded by the merged max_len.  time_mode 1 sorts on the main stream with the same count buffer,
-    // so there the chain stays in line.
+    // Local lengths: the chain runs on the auxiliary stream beside the tables kernel (time_mode 1 sorts on the main
+    // stream with the same count buffer, so there it stays in line).  Which passes run: decided by the host when it
+    // knows the largest key (`pre` below), else on the device by a word that bounds every key (no host round trip).
+    // When every read of the run came through finalize_reads, lens32 and that gate are complete behind the last of those
+    // kernels (ev_reads); otherwise the extremes kernel writes lens32 and max_buf[0] is the gate (fork at ev_max).
+    // Gathered lengths of other ranks are bounded by the merged max_len.
     const bool local = dlens == c->ra.lens32;
     const bool early = local && c->lens_early;
     hipStream_t ss = (local && c->cfg.time_mode == 0) ? c->aux : s;
