@@ -59,6 +59,7 @@ struct ppqc_ctx {
     bool init_on_aux = false;   // the last clear of the result buffer went to the auxiliary stream
     bool res_clean = false;  // ppqc_reset cleared the result buffer on the main stream and nothing has used it since
     hipEvent_t fin_start = nullptr, sort_start = nullptr;   // start events of the finalize / sort timings of this step
+    bool fin_pending = false; // the last finalize's events have not been turned into timings yet
     bool end_split = false;  // the finalize ended on two streams: its end is the later of ev_t1 and sort_end
     bool res_busy = false;   // a finalize phase (or a caller's collective on the tables) may still run: set by every
                              // finalize phase, cleared when the stream has been synchronised
@@ -403,6 +404,8 @@ int ppqc_free_pinned(void* p) {
     return PPQC_OK;
 }
 
+static int resolve_batch_timings(ppqc_ctx* c, hipEvent_t first_of_last_batch, bool keep_last);
+
 // Enqueue the per-read kernels for a batch whose arrays are all in device memory.
 static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     const uint64_t R = b->n_reads;
@@ -423,6 +426,7 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     EvPair ev{get_event(c), get_event(c), 2 * b->n_bytes + 50 * R};
     if (!ev.a || !ev.b) return fail(PPQC_E_HIP, "hipEventCreate failed");
     HIPCHK(hipEventRecord(ev.a, s));
+    hipEvent_t prev_a = c->last_a;
     c->last_a = ev.a;
     HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->n_cu, s));
     HIPCHK(hipEventRecord(ev.b, s));
@@ -443,6 +447,9 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
         HIPCHK(hipEventRecord(c->ev_pre, c->aux));
         HIPCHK(hipStreamWaitEvent(s, c->ev_pre, 0));
     }
+    // first batch behind ppqc_reset: the last run's batches are complete (the reset synchronised), and the host has
+    // nothing to do while this batch runs
+    if (c->n_reads == 0) CHK(resolve_batch_timings(c, prev_a, true));
     HIPCHK(hipEventRecord(c->ev_reads, s));
     c->n_reads += R;
     c->state = 0;
@@ -630,14 +637,33 @@ int ppqc_submit_records(ppqc_ctx* c, const ppqc_records* r) {
     return PPQC_OK;
 }
 
-static int resolve_timings(ppqc_ctx* c) {
-    if (c->last_a) {   // newest batch: tile kernel + finalize_reads
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c->last_a, c->ev_reads) == hipSuccess) c->timing.submit_ms_last = ms;
-        (void)hipGetLastError();
-        c->last_a = nullptr;
+// Event arithmetic costs the host a few microseconds per pair, so none of it happens between a step's last
+// synchronisation and the next step's first launch: the finished batches are accounted for behind the next batch's
+// launches (or when the timings are asked for), the finalize behind the next finalize's start.
+static void resolve_finalize_timings(ppqc_ctx* c) {
+    if (!c->fin_pending) return;
+    c->fin_pending = false;
+    float ms = 0.f;
+    hipEvent_t f0 = c->fin_start ? c->fin_start : c->ev_t0, s0 = c->sort_start ? c->sort_start : c->ev_s0;
+    if (hipEventElapsedTime(&ms, f0, c->ev_t1) == hipSuccess) {
+        float ms2 = 0.f;
+        if (c->end_split && c->sort_end && hipEventElapsedTime(&ms2, f0, c->sort_end) == hipSuccess && ms2 > ms) ms = ms2;
+        c->timing.finalize_ms_last = ms;
     }
-    for (auto& p : c->pending) {
+    if (hipEventElapsedTime(&ms, s0, c->sort_end ? c->sort_end : c->ev_s1) == hipSuccess) c->timing.sort_ms_last = ms;
+    (void)hipGetLastError();   // an unrecorded event is not an error of the caller
+}
+
+// Batches whose events have completed; `keep_last`: the newest pair belongs to a batch just enqueued.
+static int resolve_batch_timings(ppqc_ctx* c, hipEvent_t first_of_last_batch, bool keep_last) {
+    if (first_of_last_batch) {   // newest finished batch: tile kernel + finalize_reads
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, first_of_last_batch, c->ev_reads) == hipSuccess) c->timing.submit_ms_last = ms;
+        (void)hipGetLastError();
+    }
+    const size_t n = c->pending.size() - ((keep_last && !c->pending.empty()) ? 1 : 0);
+    for (size_t k = 0; k < n; ++k) {
+        EvPair& p = c->pending[k];
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
         c->timing.tile_kernel_ms_total += ms;
@@ -646,7 +672,15 @@ static int resolve_timings(ppqc_ctx* c) {
         c->ev_pool.push_back(p.a);
         c->ev_pool.push_back(p.b);
     }
-    c->pending.clear();
+    c->pending.erase(c->pending.begin(), c->pending.begin() + n);
+    return PPQC_OK;
+}
+
+static int resolve_timings(ppqc_ctx* c) {   // everything, behind a synchronisation
+    hipEvent_t a = c->last_a;
+    c->last_a = nullptr;
+    CHK(resolve_batch_timings(c, a, false));
+    resolve_finalize_timings(c);
     return PPQC_OK;
 }
 
@@ -656,7 +690,7 @@ int ppqc_sync(ppqc_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 2; ++i) c->slot[i].busy = false;
     c->res_busy = false;
-    return resolve_timings(c);
+    return PPQC_OK;
 }
 
 int ppqc_input_errors(ppqc_ctx* c, uint64_t* out4) {
@@ -703,6 +737,7 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    resolve_finalize_timings(c);   // its events are about to be recorded again
     c->sum_fetched = false;
     // The result buffer is cleared on the auxiliary stream: this call is usually enqueued while the per-read kernels of
     // the batch still run, and nothing before the extremes kernel touches the results, so the clear costs no time on
@@ -804,6 +839,7 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     hipStream_t s = c->stream;
     if (!dlens) { dlens = c->ra.lens32; n = c->n_reads; }
     if (n >= (1ull << 32)) return fail(PPQC_E_RANGE, "more than 2^32-1 lengths");
+    resolve_finalize_timings(c);
     // Local lengths: the chain runs on the auxiliary stream beside the tables kernel (time_mode 1 sorts on the main
     // stream with the same count buffer, so there it stays in line).  Which passes run: decided by the host when it
     // knows the largest key (`pre` below), else on the device by a word that bounds every key (no host round trip).
@@ -896,15 +932,7 @@ static int fetch_tables_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
     o->min_pos_len = mn[0];
     o->lin_bin_width = mx[0] / PPQC_N_LEN_LIN + 1;
     o->n50 = c->n50 = n50_in_mirror ? h[c->res_words + 3] : (mn + 1 + nch)[2];
-    float ms = 0.f;
-    hipEvent_t f0 = c->fin_start ? c->fin_start : c->ev_t0, s0 = c->sort_start ? c->sort_start : c->ev_s0;
-    if (hipEventElapsedTime(&ms, f0, c->ev_t1) == hipSuccess) {
-        float ms2 = 0.f;
-        if (c->end_split && c->sort_end && hipEventElapsedTime(&ms2, f0, c->sort_end) == hipSuccess && ms2 > ms) ms = ms2;
-        c->timing.finalize_ms_last = ms;
-    }
-    if (hipEventElapsedTime(&ms, s0, c->sort_end ? c->sort_end : c->ev_s1) == hipSuccess) c->timing.sort_ms_last = ms;
-    (void)hipGetLastError();   // an unrecorded event is not an error of the caller
+    c->fin_pending = true;   // timings: see resolve_finalize_timings
     return PPQC_OK;
 }
 
@@ -1020,6 +1048,7 @@ int ppqc_set_stream(ppqc_ctx* c, void* stream, int use_external) {
 int ppqc_timings(ppqc_ctx* c, ppqc_timing* o) {
     if (!c || !o) return fail(PPQC_E_INVALID, "null argument");
     CHK(ppqc_sync(c));
+    CHK(resolve_timings(c));
     *o = c->timing;
     return PPQC_OK;
 }
@@ -1027,6 +1056,7 @@ int ppqc_timings(ppqc_ctx* c, ppqc_timing* o) {
 int ppqc_reset_timings(ppqc_ctx* c) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     CHK(ppqc_sync(c));
+    CHK(resolve_timings(c));
     c->timing = ppqc_timing{};
     return PPQC_OK;
 }

@@ -185,28 +185,32 @@ class QCContext:
         return out
 
     def _tables_view(self, t):
-        """Tables as zero-copy numpy views of the context's pinned host result buffer (filled by a *_view call)."""
-        if getattr(self, "_layout", None) is None:
+        """Tables as zero-copy numpy views of the context's pinned host result buffer (filled by a *_view call).  The
+        buffer and its layout do not move, so the arrays are made once per context; a call only fills in the scalars."""
+        base = int(t.totals)
+        cache = getattr(self, "_view_cache", None)
+        if cache is None or cache[0] != base:
             d = L.DeviceTables()
             L.check(self._lib.ppqc_device_tables_view(self._ctx, C.byref(d)))
-            self._layout = int(d.n_sum + d.n_sel + d.n_max + d.n_min + 8)
-            self._res_base, self._res = None, None
-        base = int(t.totals)
-        if self._res_base != base:
-            self._res = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_int64)), shape=(self._layout,))
-            self._res_base = base
-        nch, nmux, nb = self.cfg.n_channels, self.cfg.n_mux, self.cfg.n_time_bins
-        sizes = dict(totals=L.N_TOTALS, len_hist_log2=L.N_LEN_LOG2, len_hist_lin=L.N_LEN_LIN, q_hist=L.N_QHIST,
-                     gc_hist=L.N_GCHIST, hour_reads=nb, hour_bases=nb, chan_reads=nch, chan_bases=nch, chan_fail=nch,
-                     cmh_reads=nch * nmux * nb, cmh_bases=nch * nmux * nb, chan_min_len=nch, chan_max_len=nch)
-        out = {}
-        for k, n in sizes.items():
-            o = (int(getattr(t, k)) - base) // 8
-            out[k] = self._res[o:o + n]
-        out["cmh_reads"] = out["cmh_reads"].reshape(nch, nmux, nb)
-        out["cmh_bases"] = out["cmh_bases"].reshape(nch, nmux, nb)
-        out.update(max_len=int(t.max_len), min_pos_len=int(t.min_pos_len), lin_bin_width=int(t.lin_bin_width),
-                   n50=int(t.n50))
+            words = int(d.n_sum + d.n_sel + d.n_max + d.n_min + 8)
+            res = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_int64)), shape=(words,))
+            nch, nmux, nb = self.cfg.n_channels, self.cfg.n_mux, self.cfg.n_time_bins
+            sizes = dict(totals=L.N_TOTALS, len_hist_log2=L.N_LEN_LOG2, len_hist_lin=L.N_LEN_LIN, q_hist=L.N_QHIST,
+                         gc_hist=L.N_GCHIST, hour_reads=nb, hour_bases=nb, chan_reads=nch, chan_bases=nch,
+                         chan_fail=nch, cmh_reads=nch * nmux * nb, cmh_bases=nch * nmux * nb, chan_min_len=nch,
+                         chan_max_len=nch)
+            arrays = {}
+            for k, n in sizes.items():
+                o = (int(getattr(t, k)) - base) // 8
+                arrays[k] = res[o:o + n]
+            arrays["cmh_reads"] = arrays["cmh_reads"].reshape(nch, nmux, nb)
+            arrays["cmh_bases"] = arrays["cmh_bases"].reshape(nch, nmux, nb)
+            cache = self._view_cache = (base, arrays)
+        out = dict(cache[1])
+        out["max_len"] = int(t.max_len)
+        out["min_pos_len"] = int(t.min_pos_len)
+        out["lin_bin_width"] = int(t.lin_bin_width)
+        out["n50"] = int(t.n50)
         return out
 
     def finalize(self, copy=True):
