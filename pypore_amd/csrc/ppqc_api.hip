@@ -129,9 +129,13 @@ template <typename T>
 static int grow(T** p, uint64_t old_n, uint64_t new_cap, hipStream_t s) {
     T* q = nullptr;
     HIPCHK(hipMalloc((void**)&q, new_cap * sizeof(T) + 64));
-    if (*p && old_n) HIPCHK(hipMemcpyAsync(q, *p, old_n * sizeof(T), hipMemcpyDeviceToDevice, s));
     if (*p) {
-        HIPCHK(hipStreamSynchronize(s));
+        hipError_t e = old_n ? hipMemcpyAsync(q, *p, old_n * sizeof(T), hipMemcpyDeviceToDevice, s) : hipSuccess;
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {   // the old array stays valid; the new one must not leak
+            (void)hipFree(q);
+            return fail(PPQC_E_HIP, std::string("growing a device array: ") + hipGetErrorString(e));
+        }
         HIPCHK(hipFree(*p));
     }
     *p = q;
@@ -256,22 +260,10 @@ int ppqc_config_default(ppqc_config* cfg) {
     return PPQC_OK;
 }
 
-int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
-    if (!out || !cfg) return fail(PPQC_E_INVALID, "null argument");
-    *out = nullptr;
-    if (cfg->struct_size != sizeof(ppqc_config)) return fail(PPQC_E_INVALID, "ppqc_config.struct_size mismatch");
-    if (cfg->n_channels == 0 || cfg->n_channels > (1u << 20) || cfg->n_mux == 0 || cfg->n_mux > 255 ||
-        cfg->n_time_bins == 0 || cfg->n_time_bins > 4096 || cfg->bin_seconds == 0 || cfg->time_mode > 1)
-        return fail(PPQC_E_INVALID, "config out of range");
-    if (!(cfg->fail_q >= 0.0 && cfg->fail_q <= 93.0)) return fail(PPQC_E_INVALID, "fail_q out of range");
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-        return fail(PPQC_E_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
-    if (device < 0 || device >= n) return fail(PPQC_E_NO_DEVICE, "device index out of range");
+// Everything ppqc_create sets up after its argument checks.  Any failure returns at once: the caller then hands the
+// half-built context to ppqc_destroy, which releases whatever is there (every member starts out null).
+static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     HIPCHK(hipSetDevice(device));
-    ppqc_ctx* c = new ppqc_ctx();
-    c->device = device;
-    c->cfg = *cfg;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -335,6 +327,33 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventRecord(c->ev_clean, c->stream));
     c->res_clean = true;
     c->pre_ok = true;
+    return PPQC_OK;
+}
+
+
+int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
+    if (!out || !cfg) return fail(PPQC_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(ppqc_config)) return fail(PPQC_E_INVALID, "ppqc_config.struct_size mismatch");
+    if (cfg->n_channels == 0 || cfg->n_channels > (1u << 20) || cfg->n_mux == 0 || cfg->n_mux > 255 ||
+        cfg->n_time_bins == 0 || cfg->n_time_bins > 4096 || cfg->bin_seconds == 0 || cfg->time_mode > 1)
+        return fail(PPQC_E_INVALID, "config out of range");
+    if (!(cfg->fail_q >= 0.0 && cfg->fail_q <= 93.0)) return fail(PPQC_E_INVALID, "fail_q out of range");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(PPQC_E_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(PPQC_E_NO_DEVICE, "device index out of range");
+    ppqc_ctx* c = new (std::nothrow) ppqc_ctx();
+    if (!c) return fail(PPQC_E_NOMEM, "out of host memory");
+    c->device = device;
+    c->cfg = *cfg;
+    const int rc = create_impl(c, device, cfg);
+    if (rc != PPQC_OK) {
+        const std::string msg = g_err;   // ppqc_destroy must not replace the message of the failure
+        (void)ppqc_destroy(c);
+        (void)hipGetLastError();
+        return fail(rc, msg);
+    }
     *out = c;
     return PPQC_OK;
 }

@@ -26,9 +26,13 @@ static inline void sort_geometry(uint64_t n, uint32_t* nw, uint32_t* chunk) {
     *nw = (uint32_t)((n + c - 1) / c);
 }
 
+// Counter words that suffice for EVERY key count up to n.  The number of waves is not monotone in the key count (2^21
+// keys: 2048 chunks of 1024; 2.6 M keys: 1952 chunks of 1344), and callers size the buffer once for a capacity and then
+// sort any smaller count with it, so this is the bound, not the geometry of n itself: a chunk has at least 64 keys and
+// there are at most kMaxSortWaves chunks.
 uint64_t sort_count_words(uint64_t n) {
-    uint32_t nw, chunk;
-    sort_geometry(n ? n : 1, &nw, &chunk);
+    uint64_t nw = ((n ? n : 1) + 63) / 64;
+    if (nw > kMaxSortWaves) nw = kMaxSortWaves;
     return 256ull * nw + 256;
 }
 
@@ -165,6 +169,7 @@ static hipError_t radix_sort(const K* in, K* buf_a, K* buf_b, const uint32_t* vi
     if (n >= (1ull << 32)) return hipErrorInvalidValue;
     uint32_t NW, chunk;
     sort_geometry(n, &NW, &chunk);
+    if (256ull * NW + 256 > sort_count_words(n)) return hipErrorInvalidValue;   // the bound callers allocate by
     const unsigned blocks = (NW + 3) / 4;
     const K* src = in; K* dst = buf_a;
     const uint32_t* vsrc = vin; uint32_t* vdst = va;

@@ -204,7 +204,9 @@ def test_radix_sort_and_n50(qc, c_oracle):
     import torch
     rng = np.random.default_rng(7)
     with qc.QCContext(device=0, **BASE_CFG) as ctx:
-        for n in (1, 2, 63, 64, 65, 2047, 2048, 2049, 100_000, 3_000_001):
+        # 1.5 M then 2^21 in one context: the second count fits the capacity of the first growth but needs MORE waves than
+        # the capacity itself would (the wave count is not monotone in the key count; the counters are sized by a bound)
+        for n in (1, 2, 63, 64, 65, 2047, 2048, 2049, 100_000, 1_500_000, 1 << 21, 3_000_001):
             keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
             if n > 1000:
                 keys[: n // 3] &= 0xFFFF     # many equal high digits
