@@ -27,11 +27,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="keep timing further blocks of exactly --steps steps until this much time has been timed "
+                         "(every block bracketed the same way; the figures are means over the blocks)")
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (config 2: 1e6)")
     ap.add_argument("--mu", type=float, default=8.5172)
     ap.add_argument("--sigma", type=float, default=1.1774)
@@ -40,6 +43,10 @@ def parse():
     ap.add_argument("--seed", type=int, default=20240601)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the short end-to-end (pinned host -> GPU) leg")
+    ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the config-3 sharded leg")
+    ap.add_argument("--config3-leg", action="store_true",
+                    help="with --dist-path on one GPU: run the config-3 sharded leg too (the whole 10 M-read job on one "
+                         "rank, about 100 GB of HBM), to rehearse the N > 1 code path")
     ap.add_argument("--cpu-sample-gbases", type=float, default=0.0, help="0 = auto (2 Gbases prefix)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work timed for the cpu_baseline leg")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config4adv"])
@@ -50,39 +57,171 @@ def parse():
     ap.add_argument("--fastq", action="store_true",
                     help="FASTQ TEXT as input instead of CSR (not the headline metric): GPU tokenizer on text resident in "
                          "HBM, the same streamed from pinned host memory file by file, and the host packer for comparison")
+    ap.add_argument("--cli", action="store_true",
+                    help="wall clock of `pypore seqstats` (albacore FASTQ mode) over a synthetic FASTQ directory on tmpfs, "
+                         "beside the reference-shaped Python on the same files (not the headline metric)")
+    ap.add_argument("--cli-gbases", type=float, default=2.0)
     ap.add_argument("--dist-path", action="store_true",
                     help="with one GPU: run the step through the multi-GPU merge path (1-rank RCCL group) to time it")
-    return ap.parse_args()
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="no GPU work: N ranks over gloo go through the launch, the rendezvous, the barriers and the "
+                         "max-over-ranks / sum-over-ranks reporting of this script (the CPU test of the launcher path)")
+    ap.add_argument("--master-port", type=int, default=0, help="launcher: rendezvous port (0 = pick a free one)")
+    return ap.parse_args(argv)
 
 
-def main():
-    a = parse()
+def launch_ranks(a):
+    """`bench.py --gpus N` started plainly (no WORLD_SIZE): start the N rank processes ourselves, as one torchrun child
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...`, what the driver uses).  Decided before this
+    process has imported torch or touched HIP; the child is a child process, never an exec of this one, and its exit
+    code is ours -- a rank that fails makes the whole command fail."""
+    import socket
+    import subprocess
+    port = a.master_port
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    argv = [x for x in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank run failed (exit code %d)\n" % (a.gpus, rc))
+    return rc if rc >= 0 else 1
+
+
+def launcher_selftest(a, world, rank):
+    """The launcher path without a GPU: rendezvous, barrier-bracketed timing, MAX over ranks of the time and SUM over
+    ranks of the work -- everything main() does around the steps, with nothing computed.  Prints the JSON line with the
+    number of ranks the process group really has."""
     import torch
     import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pass
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    units = torch.tensor([1000 + rank], dtype=torch.int64)
+    dist.all_reduce(units, op=dist.ReduceOp.SUM)
+    ranks = dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({"metric": "launcher selftest (no GPU work)", "value": None, "n_gpus": world, "rccl_ranks": ranks,
+                          "backend": "gloo", "steps": a.steps, "warmup": a.warmup, "selftest": True,
+                          "units_all_ranks": int(units.item()), "max_seconds": float(dt.item())}), flush=True)
+    dist.destroy_process_group()
+    return 0
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (a.gpus, world))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    use_dist = world > 1 or a.dist_path
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from pypore_amd import qc, synth
-    from pypore_amd.merge import finalize_distributed
+def start_cpu_leg(a):
+    """The cpu_baseline leg as a child process, started BEFORE this process touches the GPU (oracle/cpu_leg.py)."""
+    import subprocess
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), "ppqc_cpu_leg_%d.npz" % os.getpid())
+    cmd = [sys.executable, "-m", "oracle.cpu_leg", "--workload", a.workload, "--reads", str(a.reads), "--mu", str(a.mu),
+           "--sigma", str(a.sigma), "--seed", str(a.seed), "--channels", str(a.channels), "--time-bins", str(a.time_bins),
+           "--sample-gbases", str(a.cpu_sample_gbases if a.cpu_sample_gbases > 0 else 2.0), "--seconds",
+           str(a.cpu_seconds), "--out", out]
+    rc = subprocess.call(cmd, cwd=ROOT)
+    if rc != 0:
+        raise SystemExit("bench.py: the cpu_baseline child failed (exit code %d)" % rc)
+    return out
 
+
+def workload_shape(a):
+    """Applies --workload to the arguments (per-GPU weak-scaling shapes; config 3's real 8-way sharding is the
+    config3_sharded leg of N > 1 runs)."""
     if a.workload == "config4":
         a.mu, a.reads = 10.1266, min(a.reads, 200_000)
     if a.workload == "config3":   # the 10 M-read PromethION run sharded 8 ways: 1.25 M reads per GPU
         a.mu, a.reads, a.channels, a.time_bins = 7.8240, 1_250_000, 3000, 72
-    seed = a.seed + 7919 * rank
     if a.workload == "config4adv":
         a.reads = min(a.reads, 200_000)
+
+
+def workload_text(a, R, n_bytes):
+    if a.workload == "config4adv":
+        shape = "99.95 %% reads of 200 b + 100 reads of 2 Mb scattered through the batch"
+    else:
+        shape = "lognormal(mu=%.4f, sigma=%.4f) clipped [1, 2e6]" % (a.mu, a.sigma)
+    return "%s: %d reads/GPU, %s, %.2f Gbases + quals per GPU, %d channels, %d hourly bins, tables + radix-sort N50 " \
+           "included" % (a.workload, R, shape, n_bytes / 1e9, a.channels, a.time_bins)
+
+
+def timed_blocks(step, fence, steps, min_seconds, reduce_max):
+    """Blocks of EXACTLY `steps` steps, each bracketed by fence() (barrier + synchronise) on both sides and reduced by
+    MAX over the ranks; further blocks until `min_seconds` have been timed, decided on the reduced time so that every
+    rank runs the same number.  Returns (mean seconds per block, blocks, last tables)."""
+    total, blocks, tables = 0.0, 0, None
+    while True:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tables = step()
+        fence()
+        total += reduce_max(time.perf_counter() - t0)
+        blocks += 1
+        if total >= min_seconds or blocks >= 10_000:
+            return total / blocks, blocks, tables
+
+
+def main():
+    a = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and a.gpus > 1:
+        return launch_ranks(a)          # nothing below has run: no torch import, no HIP call in this process
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d: refusing to run (launch as `python bench.py --gpus N` "
+                         "or through torchrun with --nproc-per-node N)\n" % (a.gpus, world))
+        return 2
+    if a.launcher_selftest:
+        return launcher_selftest(a, world, rank)
+    if a.cli:
+        return cli_mode(a)
+    workload_shape(a)
+    cpu_leg_file = None
+    if world == 1 and not a.no_cpu_baseline and not (a.fastq or a.stream):
+        cpu_leg_file = start_cpu_leg(a)       # before torch / HIP are initialised in this process
+
+    import torch
+    import torch.distributed as dist
+
+    n_dev = torch.cuda.device_count()
+    if n_dev < world or local >= n_dev:
+        sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s): refusing to run\n" % (a.gpus, n_dev))
+        return 3
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    use_dist = world > 1 or a.dist_path
+    rccl_ranks = 1
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)      # the ranks RCCL really connects, not the ones asked for
+        rccl_ranks = int(one.item())
+        if rccl_ranks != world or dist.get_world_size() != world:
+            sys.stderr.write("bench.py: RCCL sees %d ranks, --gpus %d\n" % (rccl_ranks, world))
+            return 4
+
+    from pypore_amd import qc, synth
+    from pypore_amd.merge import finalize_distributed
+
+    seed = a.seed + 7919 * rank
+    if a.workload == "config4adv":
         lens = synth.adversarial_lengths(a.reads, seed)
     else:
         lens = synth.read_lengths(a.reads, a.mu, a.sigma, seed)
@@ -126,19 +265,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_max(x):
+        if world == 1:
+            return x
+        tmax = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
     for _ in range(a.warmup):
         tables = step()
     ctx.reset_timings()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        tables = step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt, blocks, tables = timed_blocks(step, fence, a.steps, a.min_seconds, reduce_max)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
         tot = torch.tensor([n_bytes], dtype=torch.int64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_bases = int(tot.item())
@@ -149,7 +287,9 @@ def main():
     # sanity: the merged tables must account for every read and base of the job
     assert int(tables["totals"][0]) == R * world, (tables["totals"][0], R * world)
     assert int(tables["totals"][1]) == total_bases, (tables["totals"][1], total_bases)
+    n50_job = int(tables["n50"])
 
+    out = None
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         value = total_bases * a.steps / dt / 1e9
@@ -159,27 +299,111 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "Gbases/s per-read QC stats", "value": round(value, 2), "unit": "Gbases/s", "n_gpus": world,
+            "rccl_ranks": rccl_ranks if use_dist else 0,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: %d reads/GPU, lognormal(mu=%.4f, sigma=%.4f) clipped [1, 2e6], %.2f Gbases + "
-                                   "quals per GPU, %d channels, %d hourly bins, tables + radix-sort N50 included"
-                                   % (a.workload, R, a.mu, a.sigma, n_bytes / 1e9, a.channels, a.time_bins),
-                       "reads_per_gpu": R, "bases_per_gpu": n_bytes, "n50": int(tables["n50"]),
+            "timed_blocks": blocks, "timed_seconds": round(dt * blocks, 3),
+            "config": {"workload": workload_text(a, R, n_bytes),
+                       "reads_per_gpu": R, "bases_per_gpu": n_bytes, "n50": n50_job,
                        "kernel_only_gbases_per_s_per_gpu": round(n_bytes / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
                        "finalize_ms": round(tm["finalize_ms_last"], 3), "sort_ms": round(tm["sort_ms_last"], 3)},
             "roofline": {"bound": "hbm", "kernel": "tile_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": None, "kernel_ms": round(k_ms, 4), "bytes_per_launch": int(alg_bytes)},
+                         "traffic": None, "kernel_ms": round(k_ms, 4), "bytes_per_launch": int(alg_bytes),
+                         "kernel_launches_timed": int(launches)},
         }
         out["roofline"].update(pmc_traffic(int(alg_bytes)))
         if world == 1 and not a.no_h2d:
             out["config"]["end_to_end_incl_h2d"] = h2d_leg(a, torch, off, ch, mux, t, d_bases, d_quals, cfg)
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a, off, d_bases, d_quals, ctx)
-        print(json.dumps(out), flush=True)
+        if cpu_leg_file:
+            out["cpu_baseline"] = cpu_baseline(cpu_leg_file, ctx)
     ctx.close()
+    del d_bases, d_quals, d_off, d_ch, d_mux, d_t
+    if (world > 1 and not a.no_config3) or (use_dist and a.config3_leg):
+        try:
+            c3 = config3_sharded(a, torch, dist, qc, synth, finalize_distributed, dev, local, rank, world)
+        except Exception as e:      # the headline line must survive a failure of the second workload
+            c3 = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            out["config3_sharded"] = c3
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    return 0
+
+
+def config3_sharded(a, torch, dist, qc, synth, finalize_distributed, dev, local, rank, world):
+    """BASELINE config 3 as BASELINE.json words it: ONE 10 M-read PromethION-scale job (3000 channels, 72 hourly bins,
+    lognormal N50 ~ 10 kb, about 50 Gbases) sharded CONTIGUOUSLY over the ranks -- rank r holds reads
+    [r R / N, (r + 1) R / N) of the job and exactly the job's bytes for them -- merged per step by the RCCL path
+    (finalize_distributed: one fused 13.9 MB all-reduce SUM of the tables behind the per-read kernel, the small MAX and
+    the three N50-select rounds beside it).  Strong scaling: the job is the same for every N, and so are its tables
+    (n50, totals): compare them across the SCALE runs."""
+    c3 = synth.CONFIGS["config3"]
+    Rj = c3["n_reads"]
+    lens = synth.read_lengths(Rj, c3["mu"], c3["sigma"], a.seed)
+    off = synth.offsets_from_lengths(lens)
+    ch, mux, t = synth.metadata(Rj, c3["n_channels"], c3["hours"], a.seed)
+    r0, r1 = rank * Rj // world, (rank + 1) * Rj // world
+    b0, b1 = int(off[r0]), int(off[r1])
+    R, n_bytes, job_bases = r1 - r0, b1 - b0, int(off[-1])
+    cfg = dict(n_channels=c3["n_channels"], n_mux=4, n_time_bins=c3["n_time_bins"], bin_seconds=3600, time_mode=0,
+               tz_offset_s=0, ref_time_s=1_528_000_000, fail_q=7.0, max_reads_hint=R)
+    ctx = qc.QCContext(device=local, **cfg)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # byte i of the job's streams depends on (seed, i) alone, so the shard's bytes are generated in place from b0 on
+    d_bases = torch.empty(n_bytes + 64, dtype=torch.uint8, device=dev)
+    d_quals = torch.empty(n_bytes + 64, dtype=torch.uint8, device=dev)
+    ctx.synth_fill_device(d_bases.data_ptr(), d_quals.data_ptr(), b0, n_bytes, a.seed)
+    d_off = torch.from_numpy((off[r0:r1 + 1] - np.uint64(b0)).view(np.int64)).to(dev)
+    d_ch = torch.from_numpy(ch[r0:r1].view(np.int32)).to(dev)
+    d_mux = torch.from_numpy(mux[r0:r1]).to(dev)
+    d_t = torch.from_numpy(t[r0:r1]).to(dev)
+    ctx.sync()
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.reset()
+        ctx.submit_device(R, n_bytes, d_bases.data_ptr(), d_quals.data_ptr(), d_off.data_ptr(), d_ch.data_ptr(),
+                          d_mux.data_ptr(), d_t.data_ptr())
+        return finalize_distributed(ctx, dist, torch, copy=False)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_max(x):
+        tmax = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
+    for _ in range(a.warmup):
+        step()
+    ctx.reset_timings()
+    dt, blocks, tables = timed_blocks(step, fence, a.steps, a.min_seconds, reduce_max)
+    tm = ctx.timings()
+    # every read and base of the job, whatever the sharding
+    assert int(tables["totals"][0]) == Rj and int(tables["totals"][1]) == job_bases, tables["totals"][:8]
+    views, d = ctx.device_tables()
+    launches = max(1, tm["tile_kernel_launches"])
+    k_ms = tm["tile_kernel_ms_total"] / launches
+    res = {"workload": "config3: ONE job of %d reads, %.2f Gbases, lognormal(mu=%.4f, sigma=%.4f), %d channels x 4 mux x "
+                       "%d hourly bins, sharded contiguously over %d ranks (%d reads on rank 0)"
+                       % (Rj, job_bases / 1e9, c3["mu"], c3["sigma"], c3["n_channels"], c3["n_time_bins"], world, R),
+           "value": round(job_bases * a.steps / dt / 1e9, 2), "unit": "Gbases/s", "scaling": "strong", "n_gpus": world,
+           "ms_per_step": round(dt / a.steps * 1e3, 3), "steps": a.steps, "timed_blocks": blocks,
+           "table_allreduce_bytes": int(d.n_sum) * 8, "n50": int(tables["n50"]), "reads": Rj, "bases": job_bases,
+           "n_fail": int(tables["totals"][2]), "tile_kernel_ms_rank0": round(k_ms, 4),
+           "tile_kernel_GBps_rank0": round(tm["tile_kernel_bytes"] / launches / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None}
+    ctx.close()
+    return res
+
+
+def cli_mode(a):
+    raise SystemExit("bench.py --cli: not implemented yet")
 
 
 def h2d_leg(a, torch, off, ch, mux, t, d_bases, d_quals, cfg):
@@ -348,63 +572,39 @@ def fastq_mode(a, ctx, torch, off, ch, t, d_bases, d_quals):
 def pmc_traffic(alg_bytes):
     """HBM bytes per tile-kernel launch from the committed rocprofv3 PMC passes of this same command (profiles/;
     2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be collected from
-    inside the timed process, so the newest profile whose algorithmic byte count equals this run's is quoted."""
+    inside the timed process, so a committed profile is quoted -- but only one taken from a library built from the very
+    sources this one was built from (csrc_sha16) on the same algorithmic byte count; otherwise `traffic` stays null."""
     import glob
+    from pypore_amd import build
+    sha = build.source_hash()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True):
         try:
-            t = json.load(open(f)).get("tile_kernel_traffic_bytes_per_launch") or {}
+            j = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if t.get("algorithmic") == alg_bytes and t.get("total"):
-            return {"traffic": int(t["total"]), "traffic_source": "profiles/" + os.path.basename(f)}
-    return {}
+        t = j.get("tile_kernel_traffic_bytes_per_launch") or {}
+        if j.get("csrc_sha16") == sha and t.get("algorithmic") == alg_bytes and t.get("total"):
+            return {"traffic": int(t["total"]), "traffic_source": "profiles/" + os.path.basename(f), "csrc_sha16": sha}
+    return {"traffic": None, "traffic_note": "no committed PMC profile of these sources (csrc_sha16 %s)" % sha}
 
 
-def synth_meta(a, R):
-    from pypore_amd import synth
-    return synth.metadata(R, a.channels, a.time_bins, a.seed)
-
-
-def cpu_baseline(a, off, d_bases, d_quals, ctx):
-    """The C oracle ("port" of the reference's per-read arithmetic) on the host cores, on a bounded sample of the
-    same workload: a prefix of at most 2 Gbases, passed over repeatedly until about 12 s of CPU work have been
-    timed.  Also re-checks the GPU records of that prefix against it."""
-    from oracle import c_oracle as co
-    cores = min(16, os.cpu_count() or 1)
-    target = a.cpu_sample_gbases * 1e9 if a.cpu_sample_gbases > 0 else 2.0e9
-    r = int(np.searchsorted(off, np.uint64(target), side="right")) - 1
-    r = max(1, min(r, len(off) - 1))
-    nb = int(off[r])
-    hb = d_bases[:nb].cpu().numpy()
-    hq = d_quals[:nb].cpu().numpy()
-    sub = off[: r + 1].copy()
-    want = co.per_read(hb, hq, sub, nthreads=cores)          # untimed first pass: page-in + the parity re-check
+def cpu_baseline(leg_file, ctx):
+    """The figures of the cpu_baseline child (oracle/cpu_leg.py, run before the GPU was touched) plus the re-check of the
+    GPU's per-read records of the same prefix against the oracle's arrays the child left."""
+    z = np.load(leg_file)
+    res = json.loads(bytes(z["result"]).decode())
+    r = int(res["prefix_reads"])
     got = ctx.read_stats(0, r)
-    ok = all(np.array_equal(got[k], want[k]) for k in ("length", "gc", "n", "qsum"))
-    ok = ok and [(int(h) << 32) + int(l) for h, l in zip(got["err_hi"], got["err_lo"])] == [int(e) for e in want["err"]]
-    passes, dt, budget = 0, 0.0, a.cpu_seconds
-    while dt < budget and passes < 1000:
-        t0 = time.perf_counter()
-        co.per_read(hb, hq, sub, nthreads=cores)
-        dt += time.perf_counter() - t0
-        passes += 1
-    # the same statistics organised the way the reference organises them (pure Python, one task per channel on a
-    # pool of `cores` processes), on a smaller prefix: SURVEY.md 8d's "reference-shaped" figure
-    from oracle import ref_shaped
-    r2 = min(r, 200_000)
-    nb2 = int(off[r2])
-    ch, mux, t = synth_meta(a, len(off) - 1)
-    dt2, _cd = ref_shaped.run(hb[:nb2], sub[: r2 + 1], ch[:r2], mux[:r2], t[:r2], got["mean_q"][:r2], 1_528_000_000, cores)
-    shaped = {"value": round(nb2 / dt2 / 1e9, 4), "unit": "Gbases/s", "cores": cores,
-              "sample": "first %d reads (%.2f Gbases), oracle/ref_shaped.py: multiprocessing pool, one task per "
-                        "channel, GC() as six count passes, parsing_func aggregation; HDF5 / dateutil / Biopython "
-                        "record costs of the real reference excluded, %.1f s" % (r2, nb2 / 1e9, dt2)}
-    return {"value": round(nb * passes / dt / 1e9, 3), "unit": "Gbases/s", "cores": cores, "kind": "port",
-            "reference_shaped_python": shaped,
-            "sample": "first %d reads (%.2f Gbases) of the same workload x %d passes, oracle/ppqc_oracle.c per-read "
-                      "statistics, %d pthreads, %.1f s timed" % (r, nb / 1e9, passes, cores, dt),
-            "gpu_matches_cpu_on_sample": bool(ok)}
+    ok = all(np.array_equal(got[k], z[k]) for k in ("length", "gc", "n", "qsum"))
+    want_err = [(int(h) << 64) | int(l) for h, l in zip(z["err_hi"], z["err_lo"])]
+    ok = ok and [(int(h) << 32) + int(l) for h, l in zip(got["err_hi"], got["err_lo"])] == want_err
+    res["gpu_matches_cpu_on_sample"] = bool(ok)
+    try:
+        os.remove(leg_file)
+    except OSError:
+        pass
+    return res
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -61,6 +61,14 @@ def per_read(bases, quals, offsets, nthreads=1):
     return out
 
 
+def synth_fill(first, n, seed, nthreads=1):
+    """(bases, quals) for stream bytes [first, first + n): host twin of the benchmark's HBM generator."""
+    bases, quals = np.empty(int(n), np.uint8), np.empty(int(n), np.uint8)
+    lib().orc_synth_fill(_p(bases), _p(quals), C.c_uint64(int(first)), C.c_uint64(int(n)), C.c_uint64(int(seed)),
+                         C.c_int(int(nthreads)))
+    return bases, quals
+
+
 def n50(lengths):
     a = np.ascontiguousarray(lengths, dtype=np.uint32)
     return int(lib().orc_n50(_p(a), C.c_uint64(len(a))))

@@ -255,3 +255,50 @@ void orc_tables(const orc_config *cfg, uint64_t R, const uint32_t *len_in, const
     scalars[0] = max_len; scalars[1] = min_pos; scalars[2] = lin_w; scalars[3] = (int64_t)orc_n50(sel_len, R);
     free(sel_len); free(hour); free(len);
 }
+
+/* ---- synthetic workload generator (bench.py's cpu_baseline leg only) ------------------------------------------------
+ * Host twin of the counter-based generator the benchmark fills HBM with (byte i of each stream depends on (seed, i)
+ * alone: word j = i / 4, hb = mix64(seed ^ (2j) M), hq = mix64(seed ^ (2j+1) M), 16 hash bits per byte), so that the CPU
+ * leg can regenerate a prefix of the workload in a process that never touches the GPU.  No reference counterpart;
+ * tests/test_synth.py holds it to pypore_amd/synth.py:stream_bytes. */
+static uint64_t synth_mix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+typedef struct { uint8_t *bases, *quals; uint64_t first, n, seed, j0, j1; } synth_job_t;
+static void *synth_worker(void *arg) {
+    synth_job_t *s = (synth_job_t *)arg;
+    const uint64_t M = 0xD1342543DE82EF95ull;
+    for (uint64_t j = s->j0; j < s->j1; ++j) {
+        uint64_t hb = synth_mix64(s->seed ^ ((2 * j) * M)), hq = synth_mix64(s->seed ^ ((2 * j + 1) * M));
+        for (int b = 0; b < 4; ++b) {
+            uint64_t i = 4 * j + b;
+            if (i < s->first || i >= s->first + s->n) continue;
+            uint32_t v = (uint32_t)(hb >> (16 * b)) & 0xFFFFu;
+            s->bases[i - s->first] = v < 7u ? 'N' : (v < 26874u ? ((v & 1u) ? 'G' : 'C') : ((v & 1u) ? 'A' : 'T'));
+            v = (uint32_t)(hq >> (16 * b)) & 0xFFFFu;
+            int q = (int)(4u * ((v & 15u) + ((v >> 4) & 15u) + ((v >> 8) & 15u) + (v >> 12)) / 9u) - 1;
+            s->quals[i - s->first] = (uint8_t)(33 + (q < 1 ? 1 : (q > 60 ? 60 : q)));
+        }
+    }
+    return NULL;
+}
+void orc_synth_fill(uint8_t *bases, uint8_t *quals, uint64_t first, uint64_t n, uint64_t seed, int nthreads) {
+    if (!n) return;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    const uint64_t w0 = first / 4, w1 = (first + n + 3) / 4, per = (w1 - w0 + nthreads - 1) / nthreads;
+    pthread_t th[256];
+    synth_job_t jobs[256];
+    int used = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        uint64_t a = w0 + per * t, e = a + per < w1 ? a + per : w1;
+        if (a >= e) break;
+        jobs[used] = (synth_job_t){bases, quals, first, n, seed, a, e};
+        pthread_create(&th[used], NULL, synth_worker, &jobs[used]);
+        ++used;
+    }
+    for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
+}

@@ -19,6 +19,18 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the library's sources: profiles/*_pmc_hbm.json record it, and bench.py quotes a
+    profile's HBM counters only when it equals the hash of the sources the running library was built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SRC + ["ppqc_internal.hpp"]):
+        h.update(f.encode())
+        h.update(open(os.path.join(HERE, "csrc", f), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "pypore_qc.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT

@@ -34,3 +34,11 @@ def test_lengths_and_metadata():
     assert 0.005 < (mux == 0).mean() < 0.02 and (t.max() - t.min()) < 48 * 3600
     adv = synth.adversarial_lengths(200_000, 3)
     assert (adv == 2_000_000).sum() == 100 and (adv == 200).sum() == 199_900
+
+
+def test_c_generator_of_the_cpu_leg_equals_stream_bytes(c_oracle):
+    for first, n, seed, th in ((0, 10_001, 42, 1), (3, 5, 7, 4), (1001, 77_777, 20240601, 3), (1 << 33, 4096, 9, 16),
+                               (5, 0, 1, 2)):
+        b, q = synth.stream_bytes(first, n, seed)
+        cb, cq = c_oracle.synth_fill(first, n, seed, th)
+        assert np.array_equal(b, cb) and np.array_equal(q, cq), (first, n, seed, th)

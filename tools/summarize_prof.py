@@ -36,6 +36,10 @@ def main():
         fr, wr = fetch[tk[0]]["mean_KB"] * 1024, write[tk[0]]["mean_KB"] * 1024
         res["tile_kernel_traffic_bytes_per_launch"] = {"fetch_raw": fr, "fetch_corrected_x2_gfx950": 2 * fr, "write": wr,
                                                        "total": 2 * fr + wr, "algorithmic": alg}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pypore_amd import build
+    res["csrc_sha16"] = build.source_hash()   # the sources the profiled library was built from (run from the same tree)
     json.dump(res, open(prefix + "_pmc_hbm.json", "w"), indent=1)
     print(json.dumps(res.get("tile_kernel_traffic_bytes_per_launch"), indent=1))
     if ks:
