@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PPQC_ABI_VERSION 3
+#define PPQC_ABI_VERSION 4
 
 enum {
     PPQC_OK = 0,
@@ -296,6 +296,13 @@ int ppqc_reset_timings(ppqc_ctx* ctx);
 /* Stand-alone device utilities (no reference counterpart; used by bench.py and the tests).
  * Hand-written LSD radix sort of n uint32 keys in device memory (ascending, in place). */
 int ppqc_sort_u32_device(ppqc_ctx* ctx, uint32_t* device_keys, uint64_t n);
+/* No counterpart in the reference.  ppqc_sort_u32_device for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): the sort's ping-pong buffer and digit counters
+ * are a static device array inside the library (about 10.3 MB per GPU, held until the process ends), so the call
+ * allocates nothing.  At most PPQC_STATIC_SORT_MAX_KEYS keys (PPQC_E_RANGE beyond).  Every call on one GPU shares that
+ * GPU's array: calls that overlap on one GPU (two contexts, two threads) race -- serialise them. */
+#define PPQC_STATIC_SORT_MAX_KEYS (1ull << 21)
+int ppqc_sort_u32_device_static(ppqc_ctx* ctx, uint32_t* device_keys, uint64_t n);
 /* Counter-based synthetic read generator: fills device bases/quals for stream bytes [first, first+n). */
 int ppqc_synth_fill_device(ppqc_ctx* ctx, uint8_t* device_bases, uint8_t* device_quals, uint64_t first,
                            uint64_t n, uint64_t seed);

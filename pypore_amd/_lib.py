@@ -28,7 +28,7 @@ SYMBOLS = (
     "ppqc_destroy", "ppqc_reset", "ppqc_alloc_pinned", "ppqc_free_pinned", "ppqc_submit", "ppqc_submit_device", "ppqc_submit_records",
     "ppqc_sync", "ppqc_n_reads", "ppqc_read_stats", "ppqc_read_hours", "ppqc_finalize_extremes",
     "ppqc_finalize_tables", "ppqc_finalize_n50", "ppqc_fetch_tables", "ppqc_fetch_tables_view", "ppqc_finalize", "ppqc_finalize_view", "ppqc_device_tables_view",
-    "ppqc_timings", "ppqc_reset_timings", "ppqc_sort_u32_device", "ppqc_synth_fill_device", "ppqc_fastq_scan", "ppqc_fastq_pack",
+    "ppqc_timings", "ppqc_reset_timings", "ppqc_sort_u32_device", "ppqc_sort_u32_device_static", "ppqc_synth_fill_device", "ppqc_fastq_scan", "ppqc_fastq_pack",
     "ppqc_submit_fastq", "ppqc_submit_fastq_device", "ppqc_input_errors", "ppqc_time_range", "ppqc_set_ref_time", "ppqc_n50_select_hist", "ppqc_n50_select_pick", "ppqc_index_early", "ppqc_stream_wait_index", "ppqc_n50_select_early", "ppqc_set_stream",
 )
 
@@ -133,6 +133,7 @@ def load():
         "ppqc_fetch_tables_view": [P, C.POINTER(Tables)], "ppqc_device_tables_view": [P, C.POINTER(DeviceTables)],
         "ppqc_timings": [P, C.POINTER(Timing)], "ppqc_reset_timings": [P],
         "ppqc_sort_u32_device": [P, P, C.c_uint64],
+        "ppqc_sort_u32_device_static": [P, P, C.c_uint64],
         "ppqc_synth_fill_device": [P, P, P, C.c_uint64, C.c_uint64, C.c_uint64],
         "ppqc_submit_fastq": [P, P, C.c_uint64, C.c_int, C.c_uint8, C.POINTER(C.c_uint64)],
         "ppqc_input_errors": [P, P], "ppqc_time_range": [P, P], "ppqc_set_ref_time": [P, C.c_int64],

@@ -1,15 +1,29 @@
 // Host side of libpypore_qc.so: the extern "C" entry points of include/pypore_qc.h.
 // Owns all device memory, one compute stream and two copy streams (double-buffered H2D) per context.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "ppqc_internal.hpp"
 
 using namespace ppqc;
+
+// Scratch of ppqc_sort_u32_device_static, the entry point for callers that cannot allocate (include/pypore_qc.h):
+// [ping-pong keys: kStaticSortMaxKeys u32 | digit counters of the radix passes].  One copy per GPU, held until the
+// process ends.  The name is a host-side stand-in, not a device address: host code only ever uses the per-device
+// address that hipGetSymbolAddress returned (g_static_scratch), taken in ppqc_create with that device current.
+constexpr uint64_t kStaticSortMaxKeys = PPQC_STATIC_SORT_MAX_KEYS;
+constexpr uint64_t kStaticSortCountWords = 256ull * 2048 + 256;   // sort_count_words(n) never exceeds this (<= 2048 waves)
+constexpr uint64_t kStaticScratchBytes = kStaticSortMaxKeys * 4 + kStaticSortCountWords * 4;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+constexpr int kMaxDevices = 64;
+static unsigned char* g_static_scratch[kMaxDevices];   // per device; written once under g_static_mu
+static std::mutex g_static_mu;
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -264,6 +278,38 @@ int ppqc_config_default(ppqc_config* cfg) {
 // half-built context to ppqc_destroy, which releases whatever is there (every member starts out null).
 static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     HIPCHK(hipSetDevice(device));
+    {   // per-device address of the static scratch (ppqc_sort_u32_device_static), once per device
+        std::lock_guard<std::mutex> lk(g_static_mu);
+        if (device < kMaxDevices && !g_static_scratch[device]) {
+            unsigned char* p = nullptr;
+            HIPCHK(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+            size_t sym_bytes = 0;
+            HIPCHK(hipGetSymbolSize(&sym_bytes, HIP_SYMBOL(scratch)));
+            if (!p || sym_bytes != kStaticScratchBytes)
+                return fail(PPQC_E_HIP, "static scratch: symbol address / size not as built");
+            if (getenv("PPQC_DEBUG_STATIC")) {   // diagnostics: runtime-validated copies only, no kernel touches p
+                fprintf(stderr, "ppqc: static scratch of device %d at %p, %zu bytes (host stand-in %p)\n", device, (void*)p,
+                        sym_bytes, (void*)scratch);
+                hipPointerAttribute_t at;
+                const hipError_t ea = hipPointerGetAttributes(&at, p);
+                fprintf(stderr, "ppqc: hipPointerGetAttributes -> %s, type %d, device %d\n", hipGetErrorString(ea),
+                        ea == hipSuccess ? (int)at.type : -1, ea == hipSuccess ? at.device : -1);
+                (void)hipGetLastError();
+                unsigned char w[64], r[64];
+                for (int i = 0; i < 64; ++i) w[i] = (unsigned char)(i * 7 + 1);
+                const size_t offs[2] = {0, kStaticScratchBytes - 64};
+                for (size_t o : offs) {
+                    memset(r, 0, sizeof r);
+                    const hipError_t e1 = hipMemcpy(p + o, w, 64, hipMemcpyHostToDevice);
+                    const hipError_t e2 = hipMemcpy(r, p + o, 64, hipMemcpyDeviceToHost);
+                    fprintf(stderr, "ppqc: copy round trip at +%zu: %s / %s, %s\n", o, hipGetErrorString(e1),
+                            hipGetErrorString(e2), memcmp(w, r, 64) == 0 ? "same" : "DIFFERENT");
+                }
+                fflush(stderr);
+            }
+            g_static_scratch[device] = p;
+        }
+    }
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1088,6 +1134,28 @@ int ppqc_sort_u32_device(ppqc_ctx* c, uint32_t* keys, uint64_t n) {
     const uint32_t* out = keys;
     HIPCHK(sort_u32(keys, c->sk32_tmp, keys, n, c->counts, 0xFu, c->stream, &out));   // four passes end in `keys`
     if (out != keys) HIPCHK(hipMemcpyAsync(keys, out, n * 4, hipMemcpyDeviceToDevice, c->stream));
+    return PPQC_OK;
+}
+
+// The same sort for callers that cannot allocate: the ping-pong buffer and the digit counters are the file-scope
+// `scratch` array (per-device address from hipGetSymbolAddress, see create_impl).  No hipMalloc / hipFree here or in
+// anything it calls; the kernels take the scratch pointers as arguments exactly as in ppqc_sort_u32_device.  Nothing in
+// the scratch has to start at zero (every counter the scan and scatter read is written by the pass's histogram kernel).
+int ppqc_sort_u32_device_static(ppqc_ctx* c, uint32_t* keys, uint64_t n) {
+    if (!c || (!keys && n)) return fail(PPQC_E_INVALID, "null argument");
+    if (n > kStaticSortMaxKeys)
+        return fail(PPQC_E_RANGE, "ppqc_sort_u32_device_static: " + std::to_string(n) + " keys exceed the static scratch (" +
+                                      std::to_string(kStaticSortMaxKeys) + " keys); use ppqc_sort_u32_device");
+    if (c->device < 0 || c->device >= kMaxDevices || !g_static_scratch[c->device])
+        return fail(PPQC_E_STATE, "no static scratch address for this device");
+    if (sort_count_words(n ? n : 1) > kStaticSortCountWords) return fail(PPQC_E_RANGE, "counter scratch too small");
+    HIPCHK(hipSetDevice(c->device));
+    unsigned char* base = g_static_scratch[c->device];
+    uint32_t* tmp = reinterpret_cast<uint32_t*>(base);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(base + kStaticSortMaxKeys * 4);
+    const uint32_t* out = keys;
+    HIPCHK(sort_u32(keys, tmp, keys, n, counts, 0xFu, c->stream, &out));   // four passes: keys -> tmp -> keys -> tmp -> keys
+    if (out != keys) return fail(PPQC_E_STATE, "sorted keys did not end in the caller's buffer");
     return PPQC_OK;
 }
 

@@ -315,6 +315,10 @@ class QCContext:
     def sort_u32_device(self, keys_ptr, n):
         L.check(self._lib.ppqc_sort_u32_device(self._ctx, keys_ptr, int(n)))
 
+    def sort_u32_device_static(self, keys_ptr, n):
+        """The same sort without any allocation (static scratch inside the library, at most 2**21 keys)."""
+        L.check(self._lib.ppqc_sort_u32_device_static(self._ctx, keys_ptr, int(n)))
+
     def synth_fill_device(self, bases_ptr, quals_ptr, first, n, seed):
         L.check(self._lib.ppqc_synth_fill_device(self._ctx, bases_ptr, quals_ptr, int(first), int(n), int(seed)))
 
