@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PPQC_ABI_VERSION 4
+#define PPQC_ABI_VERSION 5
 
 enum {
     PPQC_OK = 0,
@@ -56,8 +56,11 @@ enum {
     PPQC_TOT_BAD_CHANNEL = 7,/* channel outside 1..n_channels: counted here and in N_READS only */
     PPQC_TOT_TIME_OOB = 8,   /* hour bin outside [0, n_time_bins): dropped from hour tables only */
     PPQC_TOT_ZERO_LEN = 9,
-    PPQC_TOT_BAD_MUX = 10    /* mux outside 1..n_mux: in channel totals, not in mux/hour/fail tables
+    PPQC_TOT_BAD_MUX = 10,   /* mux outside 1..n_mux: in channel totals, not in mux/hour/fail tables
                                 (lib/fast5_reader.py:130-137 only visits mux '1'..'4') */
+    PPQC_TOT_NO_TIME = 11    /* start time INT64_MIN ("none": a FASTQ header without start_time=), valid channel: not in
+                                the time range (ppqc_time_range), no hour bin (counted in TIME_OOB too when the mux is
+                                valid) */
 };
 
 /* Hard-coded in the reference: 512 channels (lib/seq_routines.py:905-906), 4 muxes
@@ -80,7 +83,19 @@ typedef struct ppqc_config {
     int64_t ref_time_s;    /* RefTime / RefStart in ticks (lib/seq_routines.py:819-828, multi_read_fast5_reader.py:137) */
     double fail_q;         /* 7.0 */
     uint64_t max_reads_hint; /* per-read arrays are pre-sized to this (0 = grow on demand) */
+    uint32_t compat_flags; /* PPQC_COMPAT_*: reference behaviours that are defects rather than definitions, selectable so
+                              that a drop-in can be bit-identical to the reference where it matters to the caller */
+    uint32_t reserved0;    /* 0 */
 } ppqc_config;
+
+/* channel_parser (lib/multi_read_fast5_reader.py:64-67) filters a channel's reads by mux only `if len(l) > 1`: the read of
+ * a channel that holds exactly ONE read goes into MuxProductivity of every mux '1'..'4' -- whatever its own mux is --
+ * and its fail counts once per mux.  With this bit the tables of such channels say what the reference says:
+ * chan_fail = n_mux * fail, cmh_reads / cmh_bases = (1, length) at the read's hour bin under every mux, and hour_reads /
+ * hour_bases (the sum over channels and muxes, lib/seq_routines.py:103-108) count the read n_mux times.  The totals are
+ * not changed.  Multi-GPU: like time_mode 1 it needs all reads of a channel on one rank.  The single-read worker
+ * (lib/fast5_reader.py:130-145) has no such branch. */
+#define PPQC_COMPAT_MULTI_READ_SINGLE 1u
 
 /* One CSR batch of reads (what lib/fast5_reader.py:36-71 / lib/multi_read_fast5_reader.py:89-119
  * extract per read, and the FASTQ record of lib/fastqparser.py:7-16: bases = line 2, quals = line 4).

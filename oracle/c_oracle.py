@@ -18,7 +18,7 @@ def build():
 class _Cfg(C.Structure):
     _fields_ = [("n_channels", C.c_uint32), ("n_mux", C.c_uint32), ("n_time_bins", C.c_uint32),
                 ("bin_seconds", C.c_uint32), ("time_mode", C.c_uint32), ("tz_offset_s", C.c_int64),
-                ("ref_time_s", C.c_int64), ("fail_q", C.c_double)]
+                ("ref_time_s", C.c_int64), ("fail_q", C.c_double), ("compat_flags", C.c_uint32)]
 
 
 _lib = None
@@ -78,7 +78,7 @@ def tables(stats, channel, mux, start_time_s, fail_flag=None, cfg=None):
     from . import pypore_oracle as po
     cfg = po.default_config(**(cfg or {}))
     c = _Cfg(cfg["n_channels"], cfg["n_mux"], cfg["n_time_bins"], cfg["bin_seconds"], cfg["time_mode"],
-             cfg["tz_offset_s"], cfg["ref_time_s"], cfg["fail_q"])
+             cfg["tz_offset_s"], cfg["ref_time_s"], cfg["fail_q"], cfg.get("compat_flags", 0))
     nch, nmux, nb = cfg["n_channels"], cfg["n_mux"], cfg["n_time_bins"]
     R = len(channel)
     channel = np.ascontiguousarray(channel, dtype=np.uint32)

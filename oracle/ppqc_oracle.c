@@ -140,10 +140,11 @@ typedef struct {
     int64_t tz_offset_s;
     int64_t ref_time_s;
     double fail_q;
+    uint32_t compat_flags;   /* bit 0: channel_parser's single-read channel, lib/multi_read_fast5_reader.py:64-67 */
 } orc_config;
 
 enum { TOT_N_READS, TOT_N_BASES, TOT_N_FAIL, TOT_N_GC, TOT_N_N, TOT_QSUM, TOT_N_BINNED, TOT_BAD_CHANNEL,
-       TOT_TIME_OOB, TOT_ZERO_LEN, TOT_BAD_MUX, N_TOTALS = 16 };
+       TOT_TIME_OOB, TOT_ZERO_LEN, TOT_BAD_MUX, TOT_NO_TIME, N_TOTALS = 16 };
 #define N_LEN_LOG2 40
 #define N_LEN_LIN 100
 #define N_QHIST 8
@@ -184,16 +185,22 @@ void orc_tables(const orc_config *cfg, uint64_t R, const uint32_t *len_in, const
     for (uint64_t i = 0; i < R; ++i) {
         int flagged = fail_flag && fail_flag[i];
         len[i] = flagged ? 0 : len_in[i];
+        if (start_time[i] == INT64_MIN) { hour[i] = -1; continue; }   /* no start time: no hour bin */
         int64_t sec = start_time[i] - cfg->ref_time_s + cfg->tz_offset_s;
         if (cfg->time_mode == 1) { int64_t h = floordiv(sec, cfg->bin_seconds) % 24; hour[i] = h < 0 ? h + 24 : h; }
         else hour[i] = floordiv(sec, cfg->bin_seconds);
     }
     if (cfg->time_mode == 1 && R) {
         /* per channel, in start-time order: index e > 1 and hour < previous (already fixed) hour => +24 */
+        /* reads without a start time are not part of any channel's time order */
         key_t_ *k = (key_t_ *)malloc(R * sizeof(key_t_));
-        for (uint64_t i = 0; i < R; ++i) k[i] = (key_t_){channel[i], start_time[i], i};
-        qsort(k, R, sizeof(key_t_), cmp_key);
+        uint64_t Rt = 0;
+        for (uint64_t i = 0; i < R; ++i)
+            if (start_time[i] != INT64_MIN) k[Rt++] = (key_t_){channel[i], start_time[i], i};
+        qsort(k, Rt, sizeof(key_t_), cmp_key);
         uint64_t s = 0;
+        const uint64_t R_all = R;
+        R = Rt;
         while (s < R) {
             uint64_t e = s;
             while (e < R && k[e].ch == k[s].ch) ++e;
@@ -202,6 +209,7 @@ void orc_tables(const orc_config *cfg, uint64_t R, const uint32_t *len_in, const
             s = e;
         }
         free(k);
+        R = R_all;
     }
     int64_t max_len = 0, min_pos = INT64_MAX;
     for (uint64_t i = 0; i < R; ++i) {
@@ -236,10 +244,11 @@ void orc_tables(const orc_config *cfg, uint64_t R, const uint32_t *len_in, const
         totals[TOT_N_BASES] += L; totals[TOT_N_FAIL] += fail; totals[TOT_N_GC] += gc;
         totals[TOT_N_N] += flagged ? 0 : n_in[i]; totals[TOT_QSUM] += flagged ? 0 : qsum_in[i];
         totals[TOT_ZERO_LEN] += (L == 0);
+        totals[TOT_NO_TIME] += (start_time[i] == INT64_MIN);
         len_log2[L == 0 ? 0 : 64 - __builtin_clzll((unsigned long long)L)]++;
         len_lin[L / lin_w]++;
         if (qbin >= 0) q_hist[qbin]++;
-        if (gc > 0) { int64_t b = 20 * gc / L; gc_hist[b > N_GCHIST - 1 ? N_GCHIST - 1 : b]++; }
+        if (gc > 0 && L != 0) { int64_t b = 20 * gc / L; gc_hist[b > N_GCHIST - 1 ? N_GCHIST - 1 : b]++; }
         chan_reads[c]++; chan_bases[c] += L;
         if (L < chan_min[c]) chan_min[c] = L;
         if (L > chan_max[c]) chan_max[c] = L;
@@ -251,6 +260,34 @@ void orc_tables(const orc_config *cfg, uint64_t R, const uint32_t *len_in, const
         totals[TOT_N_BINNED]++;
         hour_reads[h]++; hour_bases[h] += L;
         cmh_reads[cell]++; cmh_bases[cell] += L;
+    }
+    if (cfg->compat_flags & 1u) {
+        /* channel_parser, lib/multi_read_fast5_reader.py:64-67: `if len(l) > 1` the reads are filtered by mux, `else`
+         * MucList = l -- the only read of a channel is taken under EVERY mux '1'..'4', whatever its own mux: its fail
+         * counts once per mux (:69-70), every mux gets {hour: (1, length)} (:71-77), and FastStats' sum over channels
+         * and muxes (lib/seq_routines.py:103-108) sees it n_mux times. */
+        for (uint64_t i = 0; i < R; ++i) {
+            if (channel[i] < 1 || channel[i] > nch) continue;
+            uint32_t c = channel[i] - 1;
+            if (chan_reads[c] != 1) continue;
+            int flagged = fail_flag && fail_flag[i];
+            int64_t L = len[i];
+            int fail;
+            if (flagged) fail = 6.99 < cfg->fail_q;
+            else if (is_record && is_record[i]) fail = mean_q[i] < cfg->fail_q;
+            else if (L == 0) fail = 0.0 < cfg->fail_q;
+            else fail = (((u128)err_hi[i] << 64) | err_lo[i]) > (u128)L * thr_fail;
+            chan_fail[c] = (int64_t)nmux * fail;
+            int64_t h = hour[i];
+            if (h < 0 || h >= (int64_t)nb) continue;
+            int normal = mux[i] >= 1 && mux[i] <= nmux;
+            for (uint32_t m = 0; m < nmux; ++m) {
+                size_t cell = ((size_t)c * nmux + m) * nb + (size_t)h;
+                cmh_reads[cell] = 1; cmh_bases[cell] = L;
+            }
+            hour_reads[h] += (int64_t)nmux - normal;
+            hour_bases[h] += ((int64_t)nmux - normal) * L;
+        }
     }
     scalars[0] = max_len; scalars[1] = min_pos; scalars[2] = lin_w; scalars[3] = (int64_t)orc_n50(sel_len, R);
     free(sel_len); free(hour); free(len);

@@ -547,18 +547,19 @@ def ChannelPlotter_data(c, c_plo, summary_flag=False, n_hours=48):
 # ----------------------------------------------------------------------------------------------
 
 TOT_N_READS, TOT_N_BASES, TOT_N_FAIL, TOT_N_GC, TOT_N_N, TOT_QSUM, TOT_N_BINNED, TOT_BAD_CHANNEL, \
-    TOT_TIME_OOB, TOT_ZERO_LEN, TOT_BAD_MUX = range(11)
+    TOT_TIME_OOB, TOT_ZERO_LEN, TOT_BAD_MUX, TOT_NO_TIME = range(12)
 N_TOTALS = 16
 N_LEN_LOG2 = 40
 N_LEN_LIN = 100
 N_QHIST = 8
 N_GCHIST = 20
 I64_MAX = (1 << 63) - 1
+I64_MIN = -(1 << 63)
 
 
 def default_config(**kw):
     cfg = dict(n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=0,
-               tz_offset_s=0, ref_time_s=0, fail_q=7.0)
+               tz_offset_s=0, ref_time_s=0, fail_q=7.0, compat_flags=0)
     cfg.update(kw)
     return cfg
 
@@ -622,14 +623,16 @@ def build_tables(stats, channel, mux, start_time_s, fail_flag=None, cfg=None):
 
     good_ch = (channel >= 1) & (channel <= nch)
     good_mux = (mux >= 1) & (mux <= nmux)
-    sec = t - cfg["ref_time_s"] + cfg["tz_offset_s"]
+    no_time = t == I64_MIN                      # "none": a FASTQ header without start_time= (no hour bin, not ordered)
+    sec = np.where(no_time, 0, t) - cfg["ref_time_s"] + cfg["tz_offset_s"]
     hour = np.floor_divide(sec, cfg["bin_seconds"])
     if cfg["time_mode"] == 1:
         hour = np.mod(np.floor_divide(sec, cfg["bin_seconds"]), 24)
         for c in np.unique(channel[good_ch]):
-            idx = np.nonzero(channel == c)[0]
+            idx = np.nonzero((channel == c) & ~no_time)[0]
             idx = idx[np.argsort(t[idx], kind="stable")]
             hour[idx] = _hour_wrap([int(h) for h in hour[idx]])
+    hour[no_time] = -1
 
     totals = np.zeros(N_TOTALS, dtype=np.int64)
     len_log2 = np.zeros(N_LEN_LOG2, dtype=np.int64)
@@ -662,11 +665,12 @@ def build_tables(stats, channel, mux, start_time_s, fail_flag=None, cfg=None):
         totals[TOT_N_N] += int(nn[i])
         totals[TOT_QSUM] += int(qsum[i])
         totals[TOT_ZERO_LEN] += int(L == 0)
+        totals[TOT_NO_TIME] += int(no_time[i])
         len_log2[0 if L == 0 else L.bit_length()] += 1
         len_lin[L // lin_w] += 1
         if qbin[i] >= 0:
             q_hist[qbin[i]] += 1
-        if gc[i] > 0:
+        if gc[i] > 0 and L != 0:
             gc_hist[min(N_GCHIST - 1, (20 * int(gc[i])) // L)] += 1
         chan_reads[c] += 1
         chan_bases[c] += L
@@ -686,6 +690,22 @@ def build_tables(stats, channel, mux, start_time_s, fail_flag=None, cfg=None):
         hour_bases[h] += L
         cmh_reads[c, m, h] += 1
         cmh_bases[c, m, h] += L
+    if cfg["compat_flags"] & 1:
+        # channel_parser, multi_read_fast5_reader.py:64-67: `if len(l) > 1` filter by mux, `else: MucList = l` -- the
+        # only read of a channel is taken under every mux '1'..'4' (see parsing_func(multi_read_single_quirk=True))
+        for i in np.nonzero(sel)[0]:
+            c = int(channel[i]) - 1
+            if chan_reads[c] != 1:
+                continue
+            L, h = int(length[i]), int(hour[i])
+            chan_fail[c] = nmux * int(fail[i])
+            if h < 0 or h >= nb:
+                continue
+            normal = int(good_mux[i])
+            cmh_reads[c, :, h] = 1
+            cmh_bases[c, :, h] = L
+            hour_reads[h] += nmux - normal
+            hour_bases[h] += (nmux - normal) * L
     lens_for_n50 = np.where(sel, length, 0)
     return dict(totals=totals, len_hist_log2=len_log2, len_hist_lin=len_lin, q_hist=q_hist,
                 gc_hist=gc_hist, hour_reads=hour_reads, hour_bases=hour_bases,

@@ -18,9 +18,10 @@ N_LEN_LIN = 100
 N_QHIST = 8
 N_GCHIST = 20
 I64_MAX = (1 << 63) - 1
+COMPAT_MULTI_READ_SINGLE = 1   # PPQC_COMPAT_MULTI_READ_SINGLE
 
 TOTALS = ("n_reads", "n_bases", "n_fail", "n_gc", "n_n", "qsum", "n_binned", "bad_channel", "time_oob",
-          "zero_len", "bad_mux")
+          "zero_len", "bad_mux", "no_time")
 
 # every symbol include/pypore_qc.h declares (tests check that the built library exports all of them)
 SYMBOLS = (
@@ -43,7 +44,8 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_channels", C.c_uint32), ("n_mux", C.c_uint32),
                 ("n_time_bins", C.c_uint32), ("bin_seconds", C.c_uint32), ("time_mode", C.c_uint32),
                 ("tz_offset_s", C.c_int64), ("ref_time_s", C.c_int64),
-                ("fail_q", C.c_double), ("max_reads_hint", C.c_uint64)]
+                ("fail_q", C.c_double), ("max_reads_hint", C.c_uint64), ("compat_flags", C.c_uint32),
+                ("reserved0", C.c_uint32)]
 
 
 class Batch(C.Structure):

@@ -85,6 +85,7 @@ struct ppqc_ctx {
 
     Partial *head = nullptr, *tail = nullptr;
     uint64_t cap_tiles = 0;
+    DenseList dense{nullptr, 0};   // [2 counters, 6 spare | entries]: tiles the per-read kernel leaves to dense_kernel
 
     Slot slot[2];
 
@@ -179,6 +180,9 @@ static int ensure_tiles(ppqc_ctx* c, uint64_t n_tiles) {
     if (cap < n_tiles) cap = n_tiles;
     CHK(grow(&c->head, 0, cap, c->stream));
     CHK(grow(&c->tail, 0, cap, c->stream));
+    CHK(grow(&c->dense.base, 0, cap + 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->dense.base, 0, 64, c->stream));   // both counters; every launch leaves the next one's at zero
+    c->dense.parity = 0;
     c->cap_tiles = cap;
     return PPQC_OK;
 }
@@ -271,6 +275,7 @@ int ppqc_config_default(ppqc_config* cfg) {
     cfg->struct_size = (uint32_t)sizeof(*cfg);
     cfg->n_channels = 512; cfg->n_mux = 4; cfg->n_time_bins = 48; cfg->bin_seconds = 3600;
     cfg->time_mode = 0; cfg->tz_offset_s = 0; cfg->ref_time_s = 0; cfg->fail_q = 7.0; cfg->max_reads_hint = 0;
+    cfg->compat_flags = 0; cfg->reserved0 = 0;
     return PPQC_OK;
 }
 
@@ -341,9 +346,11 @@ static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     HIPCHK(hipMalloc((void**)&c->lut_dev, sizeof(lut)));
     HIPCHK(hipMemcpy(c->lut_dev, lut, sizeof(lut), hipMemcpyHostToDevice));
 
+
     TableParams& tp = c->tp;
     make_layout(*cfg, &tp.lay);
     tp.bin_seconds = cfg->bin_seconds; tp.time_mode = cfg->time_mode; tp.tz_offset_s = cfg->tz_offset_s;
+    tp.compat_flags = cfg->compat_flags;
     tp.ref_time_s = cfg->ref_time_s; tp.fail_q = cfg->fail_q; tp.thr_fail = q_threshold(cfg->fail_q);
     for (int j = 0; j <= PPQC_N_QHIST; ++j) tp.thr_q[j] = q_threshold(6.0 + j);
 
@@ -385,6 +392,7 @@ int ppqc_create(ppqc_ctx** out, int device, const ppqc_config* cfg) {
         cfg->n_time_bins == 0 || cfg->n_time_bins > 4096 || cfg->bin_seconds == 0 || cfg->time_mode > 1)
         return fail(PPQC_E_INVALID, "config out of range");
     if (!(cfg->fail_q >= 0.0 && cfg->fail_q <= 93.0)) return fail(PPQC_E_INVALID, "fail_q out of range");
+    if (cfg->compat_flags & ~PPQC_COMPAT_MULTI_READ_SINGLE) return fail(PPQC_E_INVALID, "unknown compat_flags bit");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(PPQC_E_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
@@ -411,7 +419,7 @@ int ppqc_destroy(ppqc_ctx* c) {
     ReadArrays& r = c->ra;
     void* ptrs[] = {r.rec_cnt, r.rec_hi, r.rec_lo, r.len, r.gc, r.nn, r.qsum, r.mean_q, r.err_hi, r.err_lo, r.flags,
                     r.channel, r.mux, r.time, r.hour, r.lens32, c->head, c->tail, c->res_buf, c->sk32, c->sk32_tmp, c->counts, c->vals, c->vals_tmp, c->sk64,
-                    c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev, c->fq.counts, c->fq.prefix,
+                    c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev, c->dense.base, c->fq.counts, c->fq.prefix,
                     c->fq.block_sums, c->fq.line_off, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->res_host) (void)hipHostFree(c->res_host);
@@ -475,11 +483,13 @@ static int resolve_batch_timings(ppqc_ctx* c, hipEvent_t first_of_last_batch, bo
 static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     const uint64_t R = b->n_reads;
     CHK(ensure_reads(c, c->n_reads + R));
-    // 64 KiB tiles for long reads; short reads make a tile's cost depend on how many reads end in it, and smaller tiles
-    // spread dense regions over more waves (measured: mean 500 B +6 % at 16 KiB, adversarial mix +20 % at 32 KiB, long
-    // reads -2 % at 32 KiB and -12 % at 16 KiB)
-    const uint64_t mean = R ? b->n_bytes / R : 0;
-    uint32_t shift = mean < 768 ? 14 : (mean < 2048 ? 15 : kDefaultTileShift);
+    // 64 KiB tiles (a tile's start-up -- the read search, the first loads -- is 3 % of its time; 12 % at 16 KiB), except
+    // for batches too small to give every wave slot of the GPU a few tiles: there the kernel's time is the time of its
+    // slowest wave, and smaller tiles shorten that (the config-4 adversarial mix, 240 MB: 0.27 -> 0.43 of the HBM peak at
+    // 16 KiB; a 4000-read batch of the streaming path, 40 MB: 2400 waves instead of 600).  Which boundary strategy a tile
+    // takes is decided per tile on the device (ppqc_tile.hip), not here.
+    uint32_t shift = kDefaultTileShift;
+    while (shift > 14 && (b->n_bytes >> shift) < 16384) --shift;
     if (const char* e = getenv("PPQC_TILE_SHIFT")) shift = (uint32_t)atoi(e);   // tuning knob for A/B runs
     if (shift < (uint32_t)kMinTileShift || shift > (uint32_t)kMaxTileShift) shift = kDefaultTileShift;
     const uint64_t n_tiles = (b->n_bytes + (1ull << shift) - 1) >> shift;
@@ -493,7 +503,7 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     HIPCHK(hipEventRecord(ev.a, s));
     hipEvent_t prev_a = c->last_a;
     c->last_a = ev.a;
-    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->n_cu, s));
+    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->dense, c->n_cu, s));
     HIPCHK(hipEventRecord(ev.b, s));
     c->pending.push_back(ev);
     static const bool pre_enabled = !(getenv("PPQC_PRE") && atoi(getenv("PPQC_PRE")) == 0);   // A/B knob
@@ -628,7 +638,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     HIPCHK(launch_nl_fill(text, n, n_lines, c->fq, c->res_buf + c->res_words, s));
     // line mode: both classifiers run over the same text, every line is a segment
     BatchView v{text, text, c->fq.line_off, n_lines, n, nullptr, shift, nullptr, nullptr, nullptr};
-    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->n_cu, s, true));
+    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->dense, c->n_cu, s, true));
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
                                  c->lut_dev, c->tp.thr_fail, c->tp.fail_q, mux, c->res_buf + c->res_words, s));
     c->n_reads += R;

@@ -67,6 +67,7 @@ struct TableLayout {
 struct TableParams {
     TableLayout lay;
     uint32_t bin_seconds, time_mode;
+    uint32_t compat_flags;
     int64_t tz_offset_s;
     int64_t ref_time_s;
     uint64_t thr_fail;         // fixed-point image of fail_q
@@ -75,8 +76,16 @@ struct TableParams {
 };
 
 // ---- launchers (each enqueues on `s`, returns the hipError of the launch) -----------------------------------------
+// Device list of the dense tiles of one launch (8 + one u64 per tile of the batch) with two counters used alternately: launch k
+// counts in counters[k & 1] and its dense kernel puts counters[(k + 1) & 1] back to zero.  launch_tile_kernel flips
+// `parity` itself, and only when it has launched a dense kernel (a launch without one -- an A/B knob -- counts nothing).
+struct DenseList {
+    uint64_t* base;   // [0], [1]: the counters; [8 ..]: one entry per tile of the batch
+    int parity;
+};
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
-                              Partial* head, Partial* tail, int n_cu, hipStream_t s, bool line_mode = false);
+                              Partial* head, Partial* tail, DenseList& dl, int n_cu, hipStream_t s,
+                              bool line_mode = false);
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint64_t thr_fail, double fail_q, uint64_t* csr_errors,
                                  uint32_t n_channels, uint64_t* gate, bool write_lens, hipStream_t s);

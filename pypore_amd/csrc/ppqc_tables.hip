@@ -78,11 +78,14 @@ __global__ __launch_bounds__(1024) void extremes_kernel(BatchView b, uint64_t ba
                 atomicMax((unsigned long long*)&max_buf[ch], (unsigned long long)L);
                 atomicMax((long long*)&min_buf[ch], ~(long long)L);
             }
-            tmin = t < tmin ? t : tmin;
-            tmax = t > tmax ? t : tmax;
-            if (tp.time_mode == 0) {
-                const int64_t h = floordiv64(t - tp.ref_time_s + tp.tz_offset_s, (int64_t)tp.bin_seconds);
-                hour = (h >= 0 && h < (int64_t)tp.lay.n_time_bins) ? (int32_t)h : -1;
+            if (t != INT64_MIN) {   // INT64_MIN: the read has no start time (a FASTQ header without start_time=):
+                                    // outside the time range, no hour bin, and no arithmetic that would overflow
+                tmin = t < tmin ? t : tmin;
+                tmax = t > tmax ? t : tmax;
+                if (tp.time_mode == 0) {
+                    const int64_t h = floordiv64(t - tp.ref_time_s + tp.tz_offset_s, (int64_t)tp.bin_seconds);
+                    hour = (h >= 0 && h < (int64_t)tp.lay.n_time_bins) ? (int32_t)h : -1;
+                }
             }
         }
         if (tp.time_mode == 0) ra.hour[g] = hour;
@@ -137,6 +140,35 @@ __global__ __launch_bounds__(256) void cmh_unpack_kernel(uint64_t* sum_buf, Tabl
     }
 }
 
+// PPQC_COMPAT_MULTI_READ_SINGLE (include/pypore_qc.h): what channel_parser makes of a channel that holds exactly one
+// read (lib/multi_read_fast5_reader.py:64-67: `if len(l) > 1` filter by mux, `else` take the read under EVERY mux).  A
+// pass over the reads behind tables_kernel / cmh_unpack_kernel: a read whose channel counted one read is that channel's
+// only contributor, so its thread rewrites the channel's cells with plain stores and tops up the hour totals (the sum
+// over channels and muxes of lib/seq_routines.py:103-108) by what the normal rule did not give them.
+__global__ __launch_bounds__(256) void compat_single_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t chn = ra.channel[i], nch = tp.lay.n_channels, nmux = tp.lay.n_mux, nb = tp.lay.n_time_bins;
+    if (chn < 1 || chn > nch) return;
+    const uint32_t c = chn - 1;
+    if (sum_buf[tp.lay.off_chan_reads + c] != 1) return;
+    const uint64_t L = ra.len[i], fail = ra.flags[i] & 1u;
+    sum_buf[tp.lay.off_chan_fail + c] = (uint64_t)nmux * fail;          // `FailedReads += 1` once per mux (:69-70)
+    const int32_t h = ra.hour[i];
+    if (h < 0 || h >= (int32_t)nb) return;
+    for (uint32_t k = 0; k < nmux; ++k) {
+        const uint64_t cell = ((uint64_t)c * nmux + k) * nb + (uint32_t)h;
+        sum_buf[tp.lay.off_cmh_reads + cell] = 1;
+        sum_buf[tp.lay.off_cmh_bases + cell] = L;
+    }
+    const uint32_t m = ra.mux[i];
+    const uint64_t extra = nmux - ((m >= 1 && m <= nmux) ? 1u : 0u);     // the normal rule counted it once, or not at all
+    if (extra) {
+        atomicAdd((unsigned long long*)&sum_buf[tp.lay.off_hour_reads + h], (unsigned long long)extra);
+        atomicAdd((unsigned long long*)&sum_buf[tp.lay.off_hour_bases + h], (unsigned long long)(extra * L));
+    }
+}
+
 // ---- pass 2: all SUM tables ------------------------------------------------------------------------------------------
 // Dynamic LDS layout (u64 first for alignment):
 //   u64 totals[16] | u64 hour_bases[nb] | u64 chan_bases[nchL] |
@@ -167,7 +199,7 @@ __global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n,
     const bool packed = cmh_packable(n, max_buf[0]);
     const bool chan_lds = nchL != 0;
 
-    uint64_t tot[PPQC_TOT_BAD_MUX + 1] = {};   // thread-local run totals, added to LDS once at the end
+    uint64_t tot[PPQC_TOT_NO_TIME + 1] = {};   // thread-local run totals, added to LDS once at the end
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         tot[PPQC_TOT_N_READS] += 1;
         const uint32_t chn = ra.channel[i];
@@ -183,6 +215,7 @@ __global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n,
         tot[PPQC_TOT_N_N] += ra.nn[i];
         tot[PPQC_TOT_QSUM] += (uint64_t)ra.qsum[i];
         tot[PPQC_TOT_ZERO_LEN] += (L == 0);
+        tot[PPQC_TOT_NO_TIME] += (ra.time[i] == INT64_MIN);
         atomicAdd(&s_log2[L == 0 ? 0 : 32 - __clz(L)], 1u);
         atomicAdd(&s_lin[L / lin_w], 1u);
         // quality histogram: bin j <=> 6+j <= mean_q < 7+j <=> L*e(7+j) < S <= L*e(6+j)  (exact integers)
@@ -198,7 +231,7 @@ __global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n,
                 if (qbin < 0 && S <= (unsigned __int128)L * tp.thr_q[j] && S > (unsigned __int128)L * tp.thr_q[j + 1]) qbin = j;
         }
         if (qbin >= 0) atomicAdd(&s_q[qbin], 1u);
-        if (gc > 0) {
+        if (gc > 0 && L != 0) {   // (a record may claim bases of an empty read: no bin, no division)
             uint32_t bin = (uint32_t)((20ull * gc) / L);
             atomicAdd(&s_gc[bin > PPQC_N_GCHIST - 1 ? PPQC_N_GCHIST - 1 : bin], 1u);
         }
@@ -224,7 +257,7 @@ __global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n,
         }
     }
 #pragma unroll
-    for (int k = 0; k <= PPQC_TOT_BAD_MUX; ++k)
+    for (int k = 0; k <= PPQC_TOT_NO_TIME; ++k)
         if (tot[k]) atomicAdd(&s_tot[k], (unsigned long long)tot[k]);
     __syncthreads();
     // flush the non-zero privatised cells
@@ -260,8 +293,11 @@ __global__ __launch_bounds__(256) void mode1_keys_kernel(ReadArrays ra, uint64_t
     const uint32_t ch = ra.channel[i];
     const bool good = ch >= 1 && ch <= tp.lay.n_channels;
     // reads with a bad channel sort behind every real channel (sentinel channel n_channels + 1) and are skipped later
-    keys[i] = good ? (((uint64_t)ch << 40) | ((uint64_t)(ra.time[i] - tminmax[0]) & 0xFFFFFFFFFFull))
-                   : ((uint64_t)(tp.lay.n_channels + 1) << 40);
+    // a read without a start time (INT64_MIN) sorts behind every timed read of its channel: it gets no hour bin and
+    // takes no part in the descent test, so the timed reads keep the positions they would have without it
+    const int64_t t = ra.time[i];
+    const uint64_t tk = t == INT64_MIN ? 0xFFFFFFFFFFull : ((uint64_t)(t - tminmax[0]) & 0xFFFFFFFFFFull);
+    keys[i] = good ? (((uint64_t)ch << 40) | tk) : ((uint64_t)(tp.lay.n_channels + 1) << 40);
     vals[i] = (uint32_t)i;
     ra.hour[i] = -1;
 }
@@ -284,7 +320,9 @@ __global__ __launch_bounds__(256) void mode1_descent_kernel(ReadArrays ra, uint6
     if (ch > tp.lay.n_channels) return;
     const uint32_t pos = (uint32_t)p - chan_start[ch - 1];
     if (pos < 2) return;
-    const int32_t h = hour_of_day(ra.time[vals[p]], tp), hp = hour_of_day(ra.time[vals[p - 1]], tp);
+    const int64_t t = ra.time[vals[p]], tprev = ra.time[vals[p - 1]];
+    if (t == INT64_MIN || tprev == INT64_MIN) return;
+    const int32_t h = hour_of_day(t, tp), hp = hour_of_day(tprev, tp);
     if (h < hp) atomicMin(&first_desc[ch - 1], pos);
 }
 
@@ -297,7 +335,9 @@ __global__ __launch_bounds__(256) void mode1_assign_kernel(ReadArrays ra, uint64
     if (ch > tp.lay.n_channels) return;
     const uint32_t pos = (uint32_t)p - chan_start[ch - 1];
     const uint32_t idx = vals[p];
-    int32_t h = hour_of_day(ra.time[idx], tp) + (pos >= first_desc[ch - 1] ? 24 : 0);
+    const int64_t t = ra.time[idx];
+    if (t == INT64_MIN) return;   // hour stays -1 (mode1_keys_kernel)
+    int32_t h = hour_of_day(t, tp) + (pos >= first_desc[ch - 1] ? 24 : 0);
     ra.hour[idx] = h < (int32_t)tp.lay.n_time_bins ? h : -1;
 }
 
@@ -370,11 +410,14 @@ static inline unsigned grid_for(uint64_t n, unsigned cap) {
     return (unsigned)(b > cap ? cap : b);
 }
 
+// 8 B of dynamic LDS per channel beside the kernel's 32 B of static words: 8000 channels stay under 64 KiB
+constexpr uint32_t kExtremesLdsChannels = 8000;
+
 hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* max_buf, uint64_t* min_buf,
                            int64_t* tminmax, bool write_lens, hipStream_t s) {
     if (n == 0) return hipSuccess;
     // a length of 2^32-1 cannot be told from "unseen" in the u32 LDS copy: lengths are < 2^32-1 by the API contract
-    const uint32_t nchL = tp.lay.n_channels <= 8192 ? tp.lay.n_channels : 0;
+    const uint32_t nchL = tp.lay.n_channels <= kExtremesLdsChannels ? tp.lay.n_channels : 0;
     hipLaunchKernelGGL(extremes_kernel<false>, dim3(grid_for(n, env_or("PPQC_EXT_BLOCKS", 256))),
                        dim3(env_or("PPQC_EXT_THREADS", 512)), (size_t)nchL * 8, s, BatchView{}, (uint64_t)0, ra, n, tp,
                        max_buf, min_buf, tminmax, nchL, write_lens ? 1 : 0, (uint64_t*)nullptr, (uint64_t*)nullptr);
@@ -386,7 +429,7 @@ hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays r
                                  uint64_t* max_buf, uint64_t* min_buf, int64_t* tminmax, uint64_t* bound,
                                  uint64_t* bound_host, hipStream_t s) {
     if (b.n_reads == 0) return hipSuccess;
-    const uint32_t nchL = tp.lay.n_channels <= 8192 ? tp.lay.n_channels : 0;
+    const uint32_t nchL = tp.lay.n_channels <= kExtremesLdsChannels ? tp.lay.n_channels : 0;
     // A small grid on purpose: the tile kernel fills every SIMD's registers (4 waves of 128), so each wave resident
     // beside it displaces one of its waves for as long as it lives, and under a saturated HBM a latency-bound wave lives
     // long.  64 x 256 threads finish well inside the tile kernel of any batch worth the trouble and cost it next to
@@ -401,10 +444,16 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
                          hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint32_t nb = tp.lay.n_time_bins;
-    // per-channel accumulators in LDS need 16 B per channel; keep the block under 64 KiB so 2 blocks fit a CU
-    const uint32_t nchL = tp.lay.n_channels <= 3584 ? tp.lay.n_channels : 0;
-    const size_t lds = 8ull * (PPQC_N_TOTALS + nb + nchL) +
-                       4ull * (PPQC_N_LEN_LOG2 + PPQC_N_LEN_LIN + PPQC_N_QHIST + PPQC_N_GCHIST + nb + 2ull * nchL);
+    // per-channel accumulators in LDS need 16 B per channel; keep the block under 64 KiB so 2 blocks fit a CU.  When
+    // channels and time bins together do not fit (3000 channels x 2048 bins), the per-channel accumulators go straight
+    // to global atomics (nchL = 0); the rest fits for every n_time_bins ppqc_create accepts (4096: 50 KiB).
+    auto lds_for = [nb](uint32_t k) {
+        return 8ull * (PPQC_N_TOTALS + nb + k) +
+               4ull * (PPQC_N_LEN_LOG2 + PPQC_N_LEN_LIN + PPQC_N_QHIST + PPQC_N_GCHIST + nb + 2ull * k);
+    };
+    uint32_t nchL = tp.lay.n_channels <= 3584 ? tp.lay.n_channels : 0;
+    if (lds_for(nchL) > 64 * 1024) nchL = 0;
+    const size_t lds = lds_for(nchL);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     // few, fat blocks: every block flushes its private tables once (measured on MI355X, config 2: 256 x 512 threads
     // 0.317 ms for the whole finalize, 512 x 256: 0.34, 2048 x 256: 0.42; PPQC_TAB_* / PPQC_EXT_* are A/B knobs)
@@ -412,6 +461,8 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
                        dim3(env_or("PPQC_TAB_THREADS", 512)), lds, s, ra, n, tp, sum_buf, max_buf, nchL);
     const uint64_t cells = (uint64_t)tp.lay.n_channels * tp.lay.n_mux * tp.lay.n_time_bins;
     hipLaunchKernelGGL(cmh_unpack_kernel, dim3(grid_for(cells, 512)), dim3(256), 0, s, sum_buf, tp.lay, n, max_buf);
+    if (tp.compat_flags & PPQC_COMPAT_MULTI_READ_SINGLE)
+        hipLaunchKernelGGL(compat_single_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ra, n, tp, sum_buf);
     return hipGetLastError();
 }
 

@@ -458,6 +458,24 @@ __device__ __forceinline__ void load_batch(uint4 (&vb)[NB], uint4 (&vq)[NB], con
     }
 }
 
+// spans [I0, I1) of the batch that starts at span s0
+template <int I0, int I1, int NB, bool NT, bool LINE>
+__device__ __forceinline__ void load_part(uint4 (&vb)[NB], uint4 (&vq)[NB], const uint8_t* __restrict__ pb,
+                                          const uint8_t* __restrict__ pq, uint32_t s0, uint32_t lane_off,
+                                          uint32_t last_vec) {
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+        uint32_t o = (s0 + i) * kSpan + lane_off;
+        o = o < last_vec ? o : last_vec;
+        const u32x4 tb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pb + o));
+        vb[i] = make_uint4(tb[0], tb[1], tb[2], tb[3]);
+        if (!LINE) {
+            const u32x4 tq = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pq + o));
+            vq[i] = make_uint4(tq[0], tq[1], tq[2], tq[3]);
+        }
+    }
+}
+
 template <int NB, bool LINE, bool VECB>
 __device__ __forceinline__ void process_batch(const uint4 (&vb)[NB], const uint4 (&vq)[NB], uint32_t s0,
                                               uint32_t n_spans, Walk& w, Acc& acc, const TileCtx& c) {
@@ -469,10 +487,23 @@ __device__ __forceinline__ void process_batch(const uint4 (&vb)[NB], const uint4
 }
 
 // NB spans per batch; NT nontemporal loads; PIPE: two register sets, the next batch is in flight while one is processed.
+// What tile_kernel needs to hand dense tiles over to dense_kernel (see "the boundary strategy is chosen per tile" below).
+// ONE 64-bit kernel argument, because the kernel has no scalar registers to spare (two more and it spills, and any
+// scratch costs it a fifth of its speed):
+//   bits [0,48)  DenseList::base -- [0], [1] the two counters, [8 ..] the entries (tile | first read << 32)
+//   bit  48      which counter this launch counts in
+//   bits [49,51) 0 = probe every tile, 1 = no tile is dense, 2 = every tile is
+//   bits [51,56) log2 of dense_len: a tile is dense when at least tile_bytes >> that many reads end inside it
+typedef uint64_t DenseOut;
+__host__ __device__ inline DenseOut make_dense_out(const uint64_t* base, int parity, uint32_t mode, uint32_t len_log2) {
+    return ((uint64_t)(uintptr_t)base & 0xFFFFFFFFFFFFull) | ((uint64_t)(parity & 1) << 48) | ((uint64_t)(mode & 3u) << 49) |
+           ((uint64_t)(len_log2 & 31u) << 51);
+}
+
 template <int NB, bool NT, bool PIPE, bool LINE, bool VECB>
 __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __restrict__ lut_g, const ReadArrays& ra,
                                           uint64_t read_base, Partial* __restrict__ head, Partial* __restrict__ tail,
-                                          uint64_t n_tiles) {
+                                          uint64_t n_tiles, const DenseOut dz = make_dense_out(nullptr, 0, 1, 10)) {
     __shared__ uint64_t lut[256];
     __shared__ uint32_t xs[4][64];
     lut[threadIdx.x] = lut_g[threadIdx.x];
@@ -501,10 +532,28 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
 
         Walk w;
         w.r = find_read(c.off, c.R, tile_start, lane);
+        // density probe: one scalar load that depends on the search like the loads of the read's start and end; it is
+        // requested in front of them and looked at behind them, so it adds no latency of its own
+        const uint32_t dmode = (uint32_t)(dz >> 49) & 3u;
+        uint64_t probe = ~0ull;
+        if (!VECB && dmode == 0) {
+            uint64_t T = tile_valid >> ((uint32_t)(dz >> 51) & 31u);
+            T = T ? T : 1;
+            probe = sload_u64(c.off, w.r + T < c.R ? w.r + T : c.R);
+        }
         w.rs = uniform_u64(c.off[w.r]);
         w.done = false;
         w.win = 0; w.win_r0 = 0; w.win_ok = false;
         w.re = VECB ? read_end(w, c, w.r) : uniform_u64(c.off[w.r + 1]);
+        if (!VECB && dmode != 1 && (dmode == 2 || probe <= tile_start + tile_valid)) {   // left to dense_kernel
+            if (lane == 0) {
+                uint64_t* base = (uint64_t*)(uintptr_t)(dz & 0xFFFFFFFFFFFFull);
+                const unsigned long long k = atomicAdd((unsigned long long*)(base + ((dz >> 48) & 1ull)), 1ull);
+                if (k < n_tiles) base[8 + k] = t | (w.r << 32);   // a count that starts at zero never gets there: the
+                                                                   // list has one entry per tile
+            }
+            continue;
+        }
         w.re_rel = rel_end(w.re, tile_start);
         w.re2 = 0;
         if (!VECB) w.re2 = sload_u64(c.off, w.r + 2 < c.R ? w.r + 2 : c.R);
@@ -532,6 +581,320 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
     }
 }
 
+// ---- the boundary strategy is chosen PER TILE -------------------------------------------------------------------------
+// A batch's mean read length says little about a tile: the adversarial mix of BASELINE config 4 (99.95 % reads of 200 b
+// + 100 reads of 2 Mb) has a mean of 1.2 kb, yet every tile is either one long read or wall-to-wall 200-byte reads.  So
+// each wave of tile_kernel classifies its own tile -- one scalar probe of the offsets behind the read search: do at least
+// tile_bytes / dense_len reads end inside this tile? -- and
+//   sparse tiles: stay in tile_kernel (boundaries_bytepar, one boundary after the other, above);
+//   dense tiles : are appended to a device list (tile, first read) and left to dense_kernel, launched behind it, whose
+//                 span_scan handles every boundary of a span at once at a cost that does not depend on their number.
+// Two kernels, not two branches of one: the fast path of tile_kernel sits at exactly 128 VGPRs with no scratch, and
+// either an inlined dense branch (spills) or a called one (the callee's register saves) gives the kernel a private
+// segment -- measured, that alone costs 22 % on config 2 with instruction-for-instruction the same hot loop.
+//
+// span_scan.  Lane v of the data owns 16 bytes of the span.  A read end inside the span cuts one lane's vector at byte x
+// (x = 0: the cut is in front of the vector).  With tot_v the lane's full sums and pre_v the sums of its first x bytes
+// (ONE masked pass for all cuts of the span; uncut lanes take x = 16, pre = tot), the lanes' contributions are
+// A_v = pre_v to the read that ends at or behind v and B_v = tot_v - pre_v (cut lanes only) to the read that begins in v.
+// P = inclusive wave scan of A (u32 pieces, six v_add_u32_dpp each: four row_shr steps, row_bcast:15, row_bcast:31).
+// The read that ends in cut lane c, the previous cut being lane p, owns P_c - P_p + B_p = P_c - G_p with G = P - B
+// (wrapping u32 arithmetic on packed pieces is exact because every true field value is in range); lane c fetches G_p
+// with one ds_bpermute per piece and STORES ITS OWN RECORD at read index r + (number of cut lanes below c).  The first
+// cut of the span has no p: its read also owns the wave-uniform carry S (what earlier spans left), which lane c adds.
+// The bytes behind the last cut become the new carry, P_63 - G_last, read out with v_readlane.  No wave reduction per
+// read, no loop over the reads: about 3.3 fast-path spans of vector work per span however many reads end in it.
+// Reads shorter than a vector (two cuts in one lane, or empty reads inside the span) fall back to one masked pass per
+// boundary for that span.
+struct Carry {   // wave-uniform: sums of the open read that are not in the per-lane accumulators
+    uint32_t gcs, n, qb;
+    uint64_t hi, lo;   // S = hi * 2^32 + lo
+};
+
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {   // inclusive; every partial sum must fit 32 bits
+    v = dpp_add_u32<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add_u32<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add_u32<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add_u32<0x118, 0xf>(v);   // row_shr:8  -> scan inside each row of 16
+    v = dpp_add_u32<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add_u32<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// Span-level sums (one 16-byte vector per stream and lane, at most 64 lanes added up) in four u32 pieces:
+//   c1 = gcs | n << 16          (each <= 1024)
+//   c2 = qb | (err >> 52) << 18 (qb <= 261120 < 2^18; err <= 2^56 per lane, so the top piece is <= 16, <= 1024 summed)
+//   e0, e1 = bits [0,26) and [26,52) of err (64 * (2^26 - 1) < 2^32)
+struct Pieces { uint32_t c1, c2, e0, e1; };
+__device__ __forceinline__ Pieces to_pieces(const Acc& a) {
+    return Pieces{a.gcs | (a.n << 16), a.qb | ((uint32_t)(a.err >> 52) << 18), (uint32_t)a.err & 0x3FFFFFFu,
+                  (uint32_t)(a.err >> 26) & 0x3FFFFFFu};
+}
+__device__ __forceinline__ uint64_t pieces_err(const Pieces& p) {
+    return (uint64_t)p.e0 + ((uint64_t)p.e1 << 26) + ((uint64_t)(p.c2 >> 18) << 52);   // < 2^63 for one span
+}
+
+// Store the open read's sums (carry + per-lane accumulators if any were used since the last boundary) and clear both.
+__device__ __forceinline__ void flush_c(Acc& acc, bool& dirty, Carry& S, int lane, uint64_t* cnt, uint64_t* hi,
+                                        uint64_t* lo) {
+    uint32_t G = S.gcs, N = S.n, Q = S.qb;
+    uint64_t H = S.hi, L = S.lo;
+    if (dirty) {
+        G += wave_sum_u32(acc.gcs); N += wave_sum_u32(acc.n); Q += wave_sum_u32(acc.qb);
+        const uint32_t E0 = wave_sum_u32((uint32_t)acc.err & 0x1FFFFFu);
+        const uint32_t E1 = wave_sum_u32((uint32_t)(acc.err >> 21) & 0x1FFFFFu);
+        const uint32_t E2 = wave_sum_u32((uint32_t)(acc.err >> 42));
+        L += (uint64_t)E0 + ((uint64_t)E1 << 21);
+        H += (uint64_t)E2 << 10;
+        acc = Acc{0, 0, 0, 0};
+        dirty = false;
+    }
+    if (lane == 0) {
+        *cnt = pack_cnt(G, N, Q);
+        *hi = H;
+        *lo = L;
+    }
+    S = Carry{0, 0, 0, 0, 0};
+}
+
+__device__ __forceinline__ void flush_read_c(Acc& acc, bool& dirty, Carry& S, const Walk& w, const TileCtx& c) {
+    const bool whole = w.rs >= c.tile_start;
+    Partial* p = &c.head[c.t];
+    const uint64_t ri = c.read_base + w.r;
+    flush_c(acc, dirty, S, c.lane, whole ? &c.ra.rec_cnt[ri] : &p->cnt, whole ? &c.ra.rec_hi[ri] : &p->hi,
+            whole ? &c.ra.rec_lo[ri] : &p->lo);
+}
+
+constexpr uint32_t kNoCut = 0xFFFFFFFFu;
+
+__device__ __forceinline__ void span_scan(const uint4& vb, const uint4& vq, uint32_t span_rel, Walk& w, Acc& acc,
+                                       bool& dirty, Carry& S, const TileCtx& c) {
+    const int lane = c.lane;
+    const uint64_t span_start = c.tile_start + span_rel, span_end = span_start + kSpan;
+    const uint64_t r_save = w.r, rs_save = w.rs, re_save = w.re;
+    // phase 1: tell every data lane where its vector is cut (kNoCut = not at all)
+    c.xs[lane] = kNoCut;
+    __builtin_amdgcn_wave_barrier();
+    bool conflict = false;
+    for (int round = 0;; ++round) {
+        if (!w.win_ok || w.r < w.win_r0 || w.r - w.win_r0 >= 64) {
+            uint64_t idx = w.r + 1 + (uint64_t)lane;
+            idx = idx < c.R ? idx : c.R;
+            w.win = c.off[idx];
+            w.win_r0 = w.r;
+            w.win_ok = true;
+        }
+        const int pos = (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w.r - w.win_r0));
+        // (a malformed device CSR may hold ends in front of the span: they are no cuts, the index stays in range, and
+        // finalize_reads reports the batch)
+        const bool isb = lane >= pos && w.win_r0 + (uint64_t)lane < c.R && w.win < span_end && w.win >= span_start;
+        const uint64_t nbm = __ballot(isb);
+        if (!nbm) break;
+        const uint32_t rel = isb ? (uint32_t)(w.win - span_start) : 0u;
+        const int vl = (int)(rel >> 4);
+        const int vlp = __shfl_up(vl, 1);
+        uint32_t prior = kNoCut;
+        if (round && isb) prior = c.xs[vl];   // a cut left by the previous window of this span
+        if (__ballot(isb && ((lane > pos && vlp == vl) || prior != kNoCut))) { conflict = true; break; }
+        __builtin_amdgcn_wave_barrier();
+        if (isb) c.xs[vl] = rel & 15u;
+        __builtin_amdgcn_wave_barrier();
+        const int hb = 63 - __clzll((long long)nbm);
+        w.rs = readlane_u64(w.win, hb);
+        w.r = w.win_r0 + (uint64_t)hb + 1;
+        if (hb != 63 || w.r >= c.R) break;   // else the window is used up and more reads may end in this span
+    }
+    const Acc tot = vec_sums(vb, vq, c.lut);
+    if (conflict) {
+        // reads shorter than a vector: one masked pass per boundary, from the state the span began with
+        w.r = r_save; w.rs = rs_save; w.re = re_save;
+        const int vrel = (int)(span_rel + c.lane_off);
+        Acc prev{0, 0, 0, 0};
+        do {
+            int x = (int)(uint32_t)(w.re - c.tile_start) - vrel;
+            x = x < 0 ? 0 : (x > kVec ? kVec : x);
+            const Acc f = vec_prefix(vb, vq, x, c.lut);
+            acc_add(acc, acc_sub(f, prev));
+            dirty = true;
+            prev = f;
+            flush_read_c(acc, dirty, S, w, c);
+            walk_advance<true>(w, c);
+        } while (!w.done && w.re < span_end);
+        if (!w.done) {
+            acc = acc_sub(tot, prev);
+            dirty = true;
+            if (w.re == span_end) {
+                flush_read_c(acc, dirty, S, w, c);
+                walk_advance<true>(w, c);
+            }
+        }
+        return;
+    }
+    const uint32_t myx = c.xs[lane];
+    __builtin_amdgcn_wave_barrier();
+    const bool cut = myx != kNoCut;
+    const uint64_t B = __ballot(cut);   // != 0: the span has a boundary
+    if (dirty) {   // fast-path spans since the last boundary: fold the per-lane sums into the carry, once per read
+        Carry Z = S;
+        uint32_t G = wave_sum_u32(acc.gcs), N = wave_sum_u32(acc.n), Q = wave_sum_u32(acc.qb);
+        const uint32_t E0 = wave_sum_u32((uint32_t)acc.err & 0x1FFFFFu);
+        const uint32_t E1 = wave_sum_u32((uint32_t)(acc.err >> 21) & 0x1FFFFFu);
+        const uint32_t E2 = wave_sum_u32((uint32_t)(acc.err >> 42));
+        Z.gcs += G; Z.n += N; Z.qb += Q;
+        Z.lo += (uint64_t)E0 + ((uint64_t)E1 << 21);
+        Z.hi += (uint64_t)E2 << 10;
+        S = Z;
+        acc = Acc{0, 0, 0, 0};
+        dirty = false;
+    }
+    const Acc pre = vec_prefix(vb, vq, cut ? (int)myx : kVec, c.lut);   // uncut lanes: the whole vector
+    const Pieces a = to_pieces(pre);
+    Pieces P{wave_scan_u32(a.c1), wave_scan_u32(a.c2), wave_scan_u32(a.e0), wave_scan_u32(a.e1)};
+    // G = P - B, B = tot - pre on cut lanes.  B is split into pieces AFTER the 64-bit subtraction: the pieces of a
+    // difference of error sums are not field by field non-negative, the pieces of a non-negative value are.
+    const Pieces bp = to_pieces(cut ? acc_sub(tot, pre) : Acc{0, 0, 0, 0});
+    Pieces Gq;
+    Gq.c1 = P.c1 - bp.c1;
+    Gq.c2 = P.c2 - bp.c2;
+    Gq.e0 = P.e0 - bp.e0;
+    Gq.e1 = P.e1 - bp.e1;
+    // previous cut lane
+    const uint64_t below = B & (((uint64_t)1 << lane) - 1ull);
+    const bool has_prev = below != 0;
+    const int pl = has_prev ? 63 - __clzll((long long)below) : 0;
+    Pieces X;
+    {
+        const uint32_t g1 = (uint32_t)__shfl((int)Gq.c1, pl), g2 = (uint32_t)__shfl((int)Gq.c2, pl);
+        const uint32_t g3 = (uint32_t)__shfl((int)Gq.e0, pl), g4 = (uint32_t)__shfl((int)Gq.e1, pl);
+        X.c1 = P.c1 - (has_prev ? g1 : 0u);
+        X.c2 = P.c2 - (has_prev ? g2 : 0u);
+        X.e0 = P.e0 - (has_prev ? g3 : 0u);
+        X.e1 = P.e1 - (has_prev ? g4 : 0u);
+    }
+    if (cut) {
+        uint32_t gcs = X.c1 & 0xFFFFu, nn = X.c1 >> 16, qb = X.c2 & 0x3FFFFu;
+        uint64_t lo = pieces_err(X), hi = 0;
+        const bool first = !has_prev;
+        if (first) { gcs += S.gcs; nn += S.n; qb += S.qb; lo += S.lo; hi = S.hi; }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(B >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B, 0u));
+        const uint64_t ri = c.read_base + r_save + rank;
+        const bool to_head = first && rs_save < c.tile_start;   // the read began in an earlier tile
+        Partial* p = &c.head[c.t];
+        *(to_head ? &p->cnt : &c.ra.rec_cnt[ri]) = pack_cnt(gcs, nn, qb);
+        *(to_head ? &p->hi : &c.ra.rec_hi[ri]) = hi;
+        *(to_head ? &p->lo : &c.ra.rec_lo[ri]) = lo;
+    }
+    {   // what lies behind the last cut opens the next read
+        const int cl = 63 - __clzll((long long)B);
+        Pieces L;
+        L.c1 = (uint32_t)__builtin_amdgcn_readlane((int)P.c1, 63) - (uint32_t)__builtin_amdgcn_readlane((int)Gq.c1, cl);
+        L.c2 = (uint32_t)__builtin_amdgcn_readlane((int)P.c2, 63) - (uint32_t)__builtin_amdgcn_readlane((int)Gq.c2, cl);
+        L.e0 = (uint32_t)__builtin_amdgcn_readlane((int)P.e0, 63) - (uint32_t)__builtin_amdgcn_readlane((int)Gq.e0, cl);
+        L.e1 = (uint32_t)__builtin_amdgcn_readlane((int)P.e1, 63) - (uint32_t)__builtin_amdgcn_readlane((int)Gq.e1, cl);
+        S = Carry{L.c1 & 0xFFFFu, L.c1 >> 16, L.c2 & 0x3FFFFu, 0, pieces_err(L)};
+    }
+    w.done = w.r >= c.R;
+    if (!w.done) {
+        w.re = read_end(w, c, w.r);   // >= span_end: every end in front of it has been consumed
+        w.re_rel = rel_end(w.re, c.tile_start);
+        if (w.re == span_end) {
+            flush_read_c(acc, dirty, S, w, c);
+            walk_advance<true>(w, c);
+        }
+    }
+}
+
+constexpr int kDenseSpans = 4;   // spans per batch of a dense tile (32 VGPRs of data; the boundary pass needs the rest)
+
+// The dense tiles of a batch, from the list tile_kernel left: entry = tile | first read << 32.  One tile per wave, like
+// tile_kernel (persistent grids lose to the hardware dispatcher here as there); the host does not know the count, but a
+// dense tile holds at least T = tile_bytes / dense_len read ends and every read ends in one tile, so the list has at most
+// n_reads / T + 1 entries and the grid is sized by that bound: waves beyond the count leave at once (config 2: 15 000
+// waves, 4 us).  counters[parity] is this launch's count; the other counter, last used by the previous launch (complete:
+// stream order) and next by the following one, is put back to zero here.
+template <bool LINE>
+__global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra,
+                                                       uint64_t read_base, Partial* __restrict__ head,
+                                                       Partial* __restrict__ tail, uint64_t* __restrict__ base,
+                                                       int parity) {
+    uint64_t* __restrict__ counters = base;
+    const uint64_t* __restrict__ list = base + 8;
+    constexpr int ND = kDenseSpans;
+    __shared__ uint64_t lut[256];
+    __shared__ uint32_t xs[4][64];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[parity ^ 1] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+    const uint64_t kTile = 1ull << b.tile_shift;
+    const uint64_t n_tiles = (b.n_bytes + kTile - 1) >> b.tile_shift;
+    uint64_t count = sload_u64(counters, (uint64_t)parity);
+    count = count < n_tiles ? count : n_tiles;        // never more entries than the list holds
+    if ((uint64_t)blockIdx.x * 4 >= count) return;   // whole block: nothing below needs a block-level barrier
+    TileCtx c;
+    c.read_base = read_base; c.R = b.n_reads; c.off = b.offsets; c.ra = ra; c.head = head; c.lut = lut;
+    c.lane = lane; c.lane_off = (uint32_t)lane * kVec; c.xs = &xs[wib][0];
+    for (uint64_t i = (uint64_t)blockIdx.x * 4 + wib; i < count; i += n_waves) {
+        const uint64_t e = sload_u64(list, i);
+        const uint64_t t = e & 0xFFFFFFFFull;
+        if (t >= n_tiles || (e >> 32) >= b.n_reads) continue;   // not an entry of this batch: touch nothing
+        const uint64_t tile_start = t << b.tile_shift;
+        const uint64_t remain = b.n_bytes - tile_start;
+        const uint32_t tile_valid = remain < kTile ? (uint32_t)remain : (uint32_t)kTile;
+        const uint32_t n_spans = (tile_valid + kSpan - 1) / kSpan;
+        const uint32_t last_vec = (tile_valid - 1) & ~(uint32_t)(kVec - 1);
+        const uint8_t* __restrict__ pb = b.bases + tile_start;
+        const uint8_t* __restrict__ pq = b.quals + tile_start;
+        c.t = t; c.tile_start = tile_start;
+        uint4 vb[ND], vq[ND];
+        load_part<0, ND, ND, true, LINE>(vb, vq, pb, pq, 0, c.lane_off, last_vec);
+        Walk w;
+        w.r = e >> 32;
+        w.rs = uniform_u64(c.off[w.r]);
+        w.done = false;
+        w.win = 0; w.win_r0 = 0; w.win_ok = false;
+        w.re2 = 0;
+        w.re = read_end(w, c, w.r);
+        w.re_rel = rel_end(w.re, tile_start);
+        Acc acc{0, 0, 0, 0};
+        bool dirty = false;
+        Carry S{0, 0, 0, 0, 0};
+        for (uint32_t s0 = 0; s0 < n_spans && !w.done; s0 += ND) {
+            if (s0) load_part<0, ND, ND, true, LINE>(vb, vq, pb, pq, s0, c.lane_off, last_vec);
+#pragma unroll
+            for (int k = 0; k < ND; ++k) {
+                if (s0 + k >= n_spans || w.done) break;
+                const uint32_t span_end_rel = (s0 + k + 1) * kSpan;
+                if (w.re_rel >= span_end_rel) {   // no read ends strictly inside the span
+                    Acc tot;
+                    if (LINE) {
+                        const uint32_t ty = (uint32_t)w.r & 3u;
+                        if (ty == 1u) tot = vec_sums_bases(vb[k]);
+                        else if (ty == 3u) tot = vec_sums_quals(vb[k], c.lut);
+                        else tot = Acc{0, 0, 0, 0};
+                    } else {
+                        tot = vec_sums(vb[k], vq[k], c.lut);
+                    }
+                    acc_add(acc, tot);
+                    dirty = true;
+                    if (w.re_rel == span_end_rel) {
+                        flush_read_c(acc, dirty, S, w, c);
+                        walk_advance<true>(w, c);
+                    }
+                } else {
+                    span_scan(vb[k], LINE ? vb[k] : vq[k], (s0 + k) * kSpan, w, acc, dirty, S, c);
+                }
+            }
+        }
+        if (!w.done && w.rs < tile_start + kTile && w.re > tile_start + kTile) {
+            Partial* p = w.rs >= tile_start ? &tail[t] : &head[t];
+            flush_c(acc, dirty, S, lane, &p->cnt, &p->hi, &p->lo);
+        }
+    }
+}
+
 // VECB: read boundaries of a span handled all at once (boundary_rounds) instead of one after the other.  It needs 158
 // VGPRs (3 instead of 4 waves per SIMD) and its fast path is slower, so it is a separate instantiation that the
 // launcher picks for batches of very short reads (mean below kVecbMeanLen bytes), where several reads end in most spans.
@@ -539,8 +902,8 @@ template <int NB, bool NT, bool PIPE, bool VECB>
 __global__ __launch_bounds__(256, (VECB ? 3 : 4)) void tile_kernel(BatchView b, const uint64_t* __restrict__ lut_g,
                                                                   ReadArrays ra, uint64_t read_base,
                                                                   Partial* __restrict__ head, Partial* __restrict__ tail,
-                                                                  uint64_t n_tiles) {
-    tile_body<NB, NT, PIPE, false, VECB>(b, lut_g, ra, read_base, head, tail, n_tiles);
+                                                                  uint64_t n_tiles, DenseOut dz) {
+    tile_body<NB, NT, PIPE, false, VECB>(b, lut_g, ra, read_base, head, tail, n_tiles, dz);
 }
 
 // Line mode (FASTQ text): one stream.  8 spans per batch at 5 waves per SIMD (95 VGPRs); 16 spans spill (measured
@@ -548,8 +911,8 @@ __global__ __launch_bounds__(256, (VECB ? 3 : 4)) void tile_kernel(BatchView b, 
 template <int NB, bool VECB>
 __global__ __launch_bounds__(256, (VECB ? 4 : 5))
 void tile_kernel_line(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra, uint64_t read_base,
-                      Partial* __restrict__ head, Partial* __restrict__ tail, uint64_t n_tiles) {
-    tile_body<NB, true, false, true, VECB>(b, lut_g, ra, read_base, head, tail, n_tiles);
+                      Partial* __restrict__ head, Partial* __restrict__ tail, uint64_t n_tiles, DenseOut dz) {
+    tile_body<NB, true, false, true, VECB>(b, lut_g, ra, read_base, head, tail, n_tiles, dz);
 }
 
 // One thread per read: merge the partials of reads that span tiles, define empty reads, then decode the raw sums.
@@ -620,11 +983,12 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
     if (threadIdx.x == 0 && s_max) atomicOr((unsigned long long*)&gate[blockIdx.x & (kGateWords - 1)], (unsigned long long)s_max);
 }
 
-constexpr uint64_t kVecbMeanLen = 448;   // mean read length (bytes) below which the VECB kernel is launched
+constexpr uint32_t kDenseLen = 1024;   // a tile is dense when its reads average fewer bytes than this
 
 template <int NB, bool NT, bool PIPE, bool LINE = false, bool VECB = false>
 static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
-                                      Partial* head, Partial* tail, int n_cu, int blocks_per_cu, hipStream_t s) {
+                                      Partial* head, Partial* tail, int n_cu, int blocks_per_cu, const DenseOut& dz,
+                                      hipStream_t s) {
     const uint64_t n_tiles = (b.n_bytes + (1ull << b.tile_shift) - 1) >> b.tile_shift;
     // Default: one tile per wavefront, 4 waves per block.  The hardware dispatcher then acts as the dynamic tile
     // scheduler; measured on MI355X (config 2) this beats every persistent grid: 3.07 ms vs 3.13 (64 blocks/CU),
@@ -637,42 +1001,72 @@ static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_de
     if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
     if (LINE)
         hipLaunchKernelGGL((tile_kernel_line<NB, VECB>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base,
-                           head, tail, n_tiles);
+                           head, tail, n_tiles, dz);
     else
         hipLaunchKernelGGL((tile_kernel<NB, NT, PIPE, VECB>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra,
-                           read_base, head, tail, n_tiles);
+                           read_base, head, tail, n_tiles, dz);
     return hipGetLastError();
 }
 
-// PPQC_TILE_VARIANT / PPQC_TILE_BLOCKS_PER_CU are tuning knobs for A/B measurements; the default is the shipped one.
+// The per-read kernels of one batch: tile_kernel over every tile, then dense_kernel over the tiles it left on the list.
+// Knobs for A/B measurements (tools/tile_ab.py): PPQC_TILE_DENSE = 0 | 1 makes no / every tile dense,
+// PPQC_TILE_DENSE_LEN moves the threshold, PPQC_TILE_VARIANT = 3 | 2 | 108 run one of the older single-kernel
+// instantiations (nontemporal / temporal loads / all boundaries of a span at once with a per-lane window) on every tile,
+// PPQC_TILE_BLOCKS_PER_CU a persistent grid.
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
-                              Partial* head, Partial* tail, int n_cu, hipStream_t s, bool line_mode) {
+                              Partial* head, Partial* tail, DenseList& dl, int n_cu, hipStream_t s, bool line_mode) {
     if (b.n_bytes == 0 || b.n_reads == 0) return hipSuccess;
-    if (line_mode) {
-        // segments are text lines: the same choice by mean segment length (measured on 3.97 GB of 10 kb records:
-        // 2.63 ms per tokenizer pass with the default kernel, 3.0 ms with VECB); PPQC_LINE_VECB=0|1 forces one
-        const char* lv = getenv("PPQC_LINE_VECB");
-        const bool vecb = lv ? atoi(lv) != 0 : b.n_bytes / b.n_reads < kVecbMeanLen;
-        if (vecb) return launch_tile_variant<8, true, false, true, true>(b, lut_dev, ra, read_base, head, tail, n_cu, 0, s);
-        return launch_tile_variant<8, true, false, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, 0, s);
-    }
     const char* v = getenv("PPQC_TILE_VARIANT");
     const char* bp = getenv("PPQC_TILE_BLOCKS_PER_CU");
+    const char* dm = getenv("PPQC_TILE_DENSE");
+    const char* dlen = getenv("PPQC_TILE_DENSE_LEN");
     const int bpc = bp ? atoi(bp) : 0;
     const int variant = v ? atoi(v) : 0;
-    switch (variant) {
-        case 3: return launch_tile_variant<8, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-        case 2: return launch_tile_variant<8, false, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-        case 108: return launch_tile_variant<8, true, false, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-        default: {
-            // very short reads: several boundaries per span, take the kernel that handles them all at once
-            // (threshold measured); PPQC_TILE_VECB=0|1 forces one of them for A/B runs
-            const char* vb = getenv("PPQC_TILE_VECB");
-            const bool vecb = vb ? atoi(vb) != 0 : b.n_bytes / b.n_reads < kVecbMeanLen;
-            if (vecb) return launch_tile_variant<8, true, false, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
-            return launch_tile_variant<8, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, s);
+    uint32_t mode = dm ? (atoi(dm) ? 2u : 1u) : 0u;
+    if (!dl.base || variant != 0) mode = 1;
+    uint32_t len_log2 = 0;
+    for (uint32_t d = dlen ? (uint32_t)atoi(dlen) : kDenseLen; d > 1; d >>= 1) ++len_log2;   // a power of two
+    if (len_log2 < 4) len_log2 = 4;
+    DenseOut dz = make_dense_out(dl.base, dl.parity, mode, len_log2);
+    hipError_t e;
+    if (line_mode) {
+        const char* lv = getenv("PPQC_LINE_VECB");
+        if (lv && atoi(lv) != 0) {
+            mode = 1;
+            dz = make_dense_out(dl.base, dl.parity, mode, len_log2);
+            e = launch_tile_variant<8, true, false, true, true>(b, lut_dev, ra, read_base, head, tail, n_cu, 0, dz, s);
+        } else {
+            e = launch_tile_variant<8, true, false, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, 0, dz, s);
+        }
+    } else {
+        switch (variant) {
+            case 2: e = launch_tile_variant<8, false, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, dz, s); break;
+            case 108: e = launch_tile_variant<8, true, false, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, dz, s); break;
+            default: e = launch_tile_variant<8, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, dz, s); break;
         }
     }
+    if (e != hipSuccess || mode == 1) return e;
+    // dense_kernel: one tile per wave over the list; the grid covers the most entries the list can have (see there)
+    const uint64_t n_tiles = (b.n_bytes + (1ull << b.tile_shift) - 1) >> b.tile_shift;
+    uint64_t bound = n_tiles;
+    if (mode == 0) {
+        uint64_t T = (1ull << b.tile_shift) >> len_log2;
+        T = T ? T : 1;
+        const uint64_t most = b.n_reads / T + 1;
+        if (most < bound) bound = most;
+    }
+    uint64_t blocks = (bound + 3) / 4;
+    if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+    if (line_mode)
+        hipLaunchKernelGGL(dense_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head, tail,
+                           dl.base, dl.parity);
+    else
+        hipLaunchKernelGGL(dense_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head,
+                           tail, dl.base, dl.parity);
+    e = hipGetLastError();
+    // the counters change roles only when a dense_kernel has run: it is what leaves the other counter at zero
+    if (e == hipSuccess) dl.parity ^= 1;
+    return e;
 }
 
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,

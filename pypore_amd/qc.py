@@ -30,13 +30,14 @@ class DeviceArrayView:
 
 class QCContext:
     def __init__(self, device=0, n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=0,
-                 tz_offset_s=0, ref_time_s=0, fail_q=7.0, max_reads_hint=0):
+                 tz_offset_s=0, ref_time_s=0, fail_q=7.0, max_reads_hint=0, compat_flags=0):
         self._lib = L.load()
         cfg = L.Config()
         L.check(self._lib.ppqc_config_default(C.byref(cfg)))
         cfg.n_channels, cfg.n_mux, cfg.n_time_bins, cfg.bin_seconds = n_channels, n_mux, n_time_bins, bin_seconds
         cfg.time_mode, cfg.tz_offset_s, cfg.ref_time_s, cfg.fail_q = time_mode, tz_offset_s, int(ref_time_s), fail_q
         cfg.max_reads_hint = int(max_reads_hint)
+        cfg.compat_flags = int(compat_flags)
         self.cfg = cfg
         self._ctx = C.c_void_p()
         L.check(self._lib.ppqc_create(C.byref(self._ctx), int(device), C.byref(cfg)))

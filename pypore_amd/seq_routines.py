@@ -589,15 +589,15 @@ def fastq_module(fqfolder, Fast_flag, size):
         else:
             _submit_fastq_files(ctx, files, meta)
         ctx.finalize_extremes()
-        tmin, _tmax = ctx.time_range()
-        if ctx.n_reads and tmin < -(1 << 62):
-            raise ValueError("FASTQ records without a start_time= header field")
-        ctx.set_ref_time(tmin if ctx.n_reads else 0)
+        tmin, tmax = ctx.time_range()            # over the reads that have a start time
+        ctx.set_ref_time(tmin if tmin <= tmax else 0)
         ctx.finalize_tables()
         ctx.finalize_n50()
         tables = ctx.fetch_tables()
     if int(tables["totals"][7]):
         raise ValueError("%d FASTQ records without a usable ch= header field" % int(tables["totals"][7]))
+    if int(tables["totals"][11]):
+        raise ValueError("%d FASTQ records without a start_time= header field" % int(tables["totals"][11]))
     ChannelOut = channel_dict_from_tables(tables)
     if Fast_flag:
         from . import fastq_out
@@ -611,9 +611,10 @@ def fastq_module(fqfolder, Fast_flag, size):
 # Fast5 modes: h5py loaders on the CPU pack CSR batches (lib/seq_routines.py:903-1029)
 # ---------------------------------------------------------------------------------------------------------------
 
-def _tables_from_loader(batches, ref_time, Fast_flag):
+def _tables_from_loader(batches, ref_time, Fast_flag, compat_flags=0):
     with qc.QCContext(device=device, n_channels=n_channels, n_mux=4, n_time_bins=n_hours, bin_seconds=3600,
-                      time_mode=1, tz_offset_s=local_tz_offset(), ref_time_s=int(ref_time), fail_q=7.0) as ctx:
+                      time_mode=1, tz_offset_s=local_tz_offset(), ref_time_s=int(ref_time), fail_q=7.0,
+                      compat_flags=compat_flags) as ctx:
         kept = []
         for k, b in enumerate(batches):
             if b["n_reads"] == 0:
@@ -658,7 +659,10 @@ def multifast5reader(work_dir_, file_folder, prefix_, tmp_dir, Fast_flag, size, 
     h5_open = h5_open or H5_OPEN
     files = mf5r.dir_surfer(file_folder)
     batches, ref_start = mf5r.load_batches(files, threads=size, h5_open=h5_open)
-    tables, per_read, kept = _tables_from_loader(batches, ref_start, Fast_flag)
+    # channel_parser takes the read of a single-read channel under every mux (lib/multi_read_fast5_reader.py:64-67):
+    # reproduced, so that the tables are the reference's (PPQC_COMPAT_MULTI_READ_SINGLE; fast5module has no such branch)
+    from ._lib import COMPAT_MULTI_READ_SINGLE
+    tables, per_read, kept = _tables_from_loader(batches, ref_start, Fast_flag, COMPAT_MULTI_READ_SINGLE)
     for c in np.nonzero(tables["chan_reads"] == 0)[0]:
         log.warning('Channel %s inactive!' % int(c))
     ChannelOut = channel_dict_from_tables(tables)

@@ -90,13 +90,14 @@ def test_albacore_mode_end_to_end(tmp_path, monkeypatch):
         assert (tmp_path / "res" / f).stat().st_size > 10000
 
 
-def _ref_shaped(recs, ref, tz, n_ch=512, times=None):
+def _ref_shaped(recs, ref, tz, n_ch=512, times=None, multi_read_single_quirk=False):
     tuples = []
     for k, r in enumerate(recs):
         t = times[k] if times is not None else ref + r["sec"]
         tuples.append(po.get_content_tuple(r["ch"], r["mux"], t, len(r["seq"]), _mean_q(r["qual"]), po.GC(r["seq"]),
                                            fail=bool(r.get("fail"))))
-    return po.build_channel_dict(tuples, float(ref), n_channels=n_ch, tz_offset_s=tz)
+    return po.build_channel_dict(tuples, float(ref), n_channels=n_ch, tz_offset_s=tz,
+                                 multi_read_single_quirk=multi_read_single_quirk)
 
 
 def test_fastq_only_mode_with_fastq_output(tmp_path, monkeypatch):
@@ -178,5 +179,19 @@ def test_fast5_modes_on_stand_in_hdf5(tmp_path, monkeypatch):
     fake_h5.write_multi(str(tmp_path / "m" / "fail" / "c.fast5"), [entry(r, False) for r in bad], exp)
     cd2, stats2, plates2 = sq.run([str(tmp_path), str(tmp_path / "m"), "multi", "res2", "1", "False", "2", "False",
                                    "None", "True"])
-    _check_stats(stats2, po.FastStats_data(ref_cd))
-    assert plates2 == plates and dict(cd2) == dict(cd)
+    # multi-read mode goes through channel_parser, which takes the read of a single-read channel under EVERY mux
+    # (lib/multi_read_fast5_reader.py:64-67): the expectation is built with that branch, and the fixture has such
+    # channels, failing and passing ones (300 reads over 512 channels)
+    ref_cd_m = _ref_shaped(recs, ref, sq.local_tz_offset(), times=times, multi_read_single_quirk=True)
+    singles = [c for c in range(1, 513) if ref_cd_m[str(c)] and ref_cd_m[str(c)][0] == 1]
+    assert len(singles) > 50 and any(ref_cd_m[str(c)][2] == 4 for c in singles) and \
+        any(ref_cd_m[str(c)][2] == 0 for c in singles)
+    assert po.FastStats_data(ref_cd_m)["table"] != po.FastStats_data(ref_cd)["table"]     # the branch matters here
+    _check_stats(stats2, po.FastStats_data(ref_cd_m))
+    assert plates2 == plates
+    for c in range(1, 513):
+        e, r = cd2[str(c)], ref_cd_m[str(c)]
+        assert (e == ()) == (r == ())
+        if e:
+            assert tuple(e[:3]) == tuple(r[:3]), (c, e[:3], r[:3])
+        assert sq.channel_plot_data(c, cd2) == po.ChannelPlotter_data(c, ref_cd_m)

@@ -145,6 +145,35 @@ def test_batch_time_extremes_equal_finalize_time_extremes(qc, c_oracle):
             assert_tables_equal(ctx.finalize(copy=False), wt, "behind reset")
 
 
+@pytest.mark.parametrize("seed,mode", [(31, 1), (32, 1), (33, 0)])
+def test_single_read_channel_compat_and_missing_start_times(qc, c_oracle, seed, mode):
+    """PPQC_COMPAT_MULTI_READ_SINGLE (channel_parser's `if len(l) > 1`, lib/multi_read_fast5_reader.py:64-67: the only
+    read of a channel is taken under every mux) against the oracle's table layer, which tests/test_oracle.py holds to
+    parsing_func(multi_read_single_quirk=True); and reads without a start time (INT64_MIN)."""
+    cfg = dict(BASE_CFG, time_mode=mode, n_channels=64, compat_flags=1)
+    b = random_batch(seed, 90, 200, n_channels=64, hours=47)      # most channels hold one read or none
+    assert (np.bincount(b["channel"], minlength=70)[1:65] == 1).sum() >= 10
+    b["time"] = b["time"].copy()
+    b["time"][::11] = -(1 << 63)
+    got, tables, hours = _run(qc, b, cfg, c_oracle)
+    assert int(tables["totals"][11]) == len(b["time"][::11][(b["channel"][::11] >= 1) & (b["channel"][::11] <= 64)])
+    plain = dict(cfg, compat_flags=0)
+    want = c_oracle.per_read(b["bases"], b["quals"], b["offsets"], nthreads=2)
+    wt = c_oracle.tables(want, b["channel"], b["mux"], b["time"], b["fail_flag"], plain)
+    assert not np.array_equal(np.asarray(tables["cmh_reads"]), np.asarray(wt["cmh_reads"]))    # the bit does something
+    assert np.array_equal(np.asarray(tables["chan_reads"]), np.asarray(wt["chan_reads"]))
+
+
+@pytest.mark.parametrize("n_channels,n_mux,n_time_bins", [(3000, 1, 2048), (8190, 4, 2), (8192, 2, 3), (9000, 1, 48)])
+def test_geometries_at_the_lds_limits(qc, c_oracle, n_channels, n_mux, n_time_bins):
+    """Configurations whose per-channel accumulators do not fit the kernels' LDS layouts (3000 channels x 2048 bins is
+    73 KB in tables_kernel; 8189..8192 channels overflow extremes_kernel's 64 KiB with its static words): they take the
+    global-atomic paths instead of failing at finalize time."""
+    cfg = dict(BASE_CFG, n_channels=n_channels, n_mux=n_mux, n_time_bins=n_time_bins, bin_seconds=60)
+    b = random_batch(n_channels, 3000, 150, n_channels=n_channels, hours=30)
+    _run(qc, b, cfg, c_oracle)
+
+
 def test_no_fail_flag_and_all_flagged(qc, c_oracle):
     b = random_batch(41, 800, 500)
     _run(qc, b, BASE_CFG, c_oracle, use_ff=False)

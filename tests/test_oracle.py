@@ -121,16 +121,26 @@ def test_toy_run_table_shaped_matches_reference_shaped_and_golden():
     assert t["n50"] == 2000 and t["totals"][po.TOT_BAD_MUX] == 1
 
 
-@pytest.mark.parametrize("seed,mode,tz", [(1, 1, 0), (2, 1, 3600), (3, 1, -18000)])
-def test_table_layer_equals_reference_layer_on_random_runs(seed, mode, tz):
-    """parsing_func / FastStats_data on string tuples == build_tables on arrays, including the wrap quirk."""
-    n_ch = 9
-    b = random_batch(seed, 700, 60, edge=False, n_channels=n_ch, hours=47, ref=1_528_000_000, bad_meta=False)
+@pytest.mark.parametrize("seed,mode,tz,quirk", [(1, 1, 0, False), (2, 1, 3600, False), (3, 1, -18000, False),
+                                                 (4, 1, 0, True), (5, 1, 7200, True)])
+def test_table_layer_equals_reference_layer_on_random_runs(seed, mode, tz, quirk, c_oracle):
+    """parsing_func / FastStats_data on string tuples == build_tables on arrays, including the wrap quirk and, with
+    ``quirk``, channel_parser's single-read channel (lib/multi_read_fast5_reader.py:64-67 == compat_flags bit 0)."""
+    n_ch = 9 if not quirk else 40
+    b = random_batch(seed, 700 if not quirk else 60, 60, edge=False, n_channels=n_ch, hours=47, ref=1_528_000_000,
+                     bad_meta=False)
     b["mux"][::17] = 0
+    if quirk:      # single-read channels of every kind: mux 0, flagged as failed, low quality
+        b["mux"][::5] = 0
+        b["quals"][: int(b["offsets"][len(b["channel"]) // 2])] = 33 + 3
+        counts = np.bincount(b["channel"], minlength=n_ch + 1)
+        assert (counts == 1).sum() >= 5
     st = po.per_read_stats(b["bases"], b["quals"], b["offsets"])
     cfg = dict(n_channels=n_ch, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=mode, tz_offset_s=tz,
-               ref_time_s=1_528_000_000, fail_q=7.0)
+               ref_time_s=1_528_000_000, fail_q=7.0, compat_flags=1 if quirk else 0)
     t = po.build_tables(st, b["channel"], b["mux"], b["time"], b["fail_flag"], cfg)
+    assert_tables_equal(c_oracle.tables(c_oracle.per_read(b["bases"], b["quals"], b["offsets"]), b["channel"], b["mux"],
+                                        b["time"], b["fail_flag"], cfg), t, "C oracle vs Python oracle")
     tuples = []
     for i in range(len(b["channel"])):
         a, e = int(b["offsets"][i]), int(b["offsets"][i + 1])
@@ -138,7 +148,7 @@ def test_table_layer_equals_reference_layer_on_random_runs(seed, mode, tz):
         tuples.append(po.get_content_tuple(int(b["channel"][i]), int(b["mux"][i]), int(b["time"][i]),
                                            int(st["length"][i]), float(st["mean_q"][i]),
                                            po.GC(b["bases"][a:e].tobytes()), fail=bool(b["fail_flag"][i])))
-    cd = po.build_channel_dict(tuples, 1_528_000_000.0, n_channels=n_ch, tz_offset_s=tz)
+    cd = po.build_channel_dict(tuples, 1_528_000_000.0, n_channels=n_ch, tz_offset_s=tz, multi_read_single_quirk=quirk)
     for c in range(n_ch):
         e = cd[str(c + 1)]
         assert (e[0] if e else 0) == t["chan_reads"][c] and (e[1] if e else 0) == t["chan_bases"][c]
@@ -151,10 +161,38 @@ def test_table_layer_equals_reference_layer_on_random_runs(seed, mode, tz):
     fs = po.FastStats_data(cd)
     assert [h[0] for h in fs["HoursDict"]] == t["hour_reads"].tolist()
     assert [h[1] for h in fs["HoursDict"]] == t["hour_bases"].tolist()
-    assert fs["FailSum"] == int(t["chan_fail"].sum()) and fs["PassSum"] == int(t["totals"][po.TOT_N_BINNED])
+    assert fs["FailSum"] == int(t["chan_fail"].sum()) and fs["PassSum"] == int(t["hour_reads"].sum())
+    if not quirk:
+        assert fs["PassSum"] == int(t["totals"][po.TOT_N_BINNED])
+    else:
+        assert fs["PassSum"] > int(t["totals"][po.TOT_N_BINNED])     # single-read channels count once per mux
     assert fs["BiggestRead"] == t["max_len"]
     pos = [int(x) for x in list(t["chan_min_len"]) + list(t["chan_max_len"]) if 0 < int(x) < po.I64_MAX]
     assert fs["SmallestRead"] == min(pos)
+
+
+def test_reads_without_a_start_time_have_no_hour_and_do_not_disturb_the_order(c_oracle):
+    """INT64_MIN = no start time (a FASTQ header without start_time=): counted in TOT_NO_TIME, no hour bin, and the timed
+    reads of the channel keep the hours they have without it, in both time modes."""
+    b = random_batch(21, 400, 50, edge=False, n_channels=6, hours=47, bad_meta=False)
+    st = po.per_read_stats(b["bases"], b["quals"], b["offsets"])
+    t2 = b["time"].copy()
+    gone = np.arange(len(t2)) % 9 == 4
+    t2[gone] = -(1 << 63)
+    for mode in (0, 1):
+        cfg = dict(n_channels=6, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=mode, tz_offset_s=0,
+                   ref_time_s=1_528_000_000, fail_q=7.0)
+        full = po.build_tables(st, b["channel"], b["mux"], b["time"], None, cfg)
+        some = po.build_tables(st, b["channel"], b["mux"], t2, None, cfg)
+        assert int(some["totals"][po.TOT_NO_TIME]) == int(gone.sum()) and (some["hour"][gone] == -1).all()
+        keep = ~gone
+        sub = {k: (v[keep] if isinstance(v, np.ndarray) else [x for x, g in zip(v, keep) if g]) for k, v in st.items()}
+        only = po.build_tables(sub, b["channel"][keep], b["mux"][keep], b["time"][keep], None, cfg)
+        assert np.array_equal(some["hour"][keep], only["hour"])
+        assert np.array_equal(some["cmh_reads"], only["cmh_reads"]) and np.array_equal(some["hour_bases"], only["hour_bases"])
+        assert np.array_equal(some["chan_reads"], full["chan_reads"])
+        assert_tables_equal(c_oracle.tables(c_oracle.per_read(b["bases"], b["quals"], b["offsets"]), b["channel"],
+                                            b["mux"], t2, None, cfg), some, "C oracle, mode %d" % mode)
 
 
 def test_summary_reader_and_fastq_reader():

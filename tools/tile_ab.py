@@ -38,7 +38,16 @@ ref = None
 for rnd in range(rounds + 1):
     for v in variants:
         for bpc, sh in [(x, y) for x in bpcs for y in shifts]:
-            os.environ["PPQC_TILE_VARIANT"] = v
+            # "0" = the shipped pair of kernels (per-tile probe); "0s" / "0d" force every tile sparse / dense;
+            # "0:LEN" sets the density threshold; "108" = the older one-kernel VECB instantiation
+            os.environ.pop("PPQC_TILE_DENSE", None); os.environ.pop("PPQC_TILE_DENSE_LEN", None)
+            vv = v
+            if v[0] == "0":
+                vv = "0"
+                if v.endswith("d"): os.environ["PPQC_TILE_DENSE"] = "1"
+                if v.endswith("s"): os.environ["PPQC_TILE_DENSE"] = "0"
+                if ":" in v: os.environ["PPQC_TILE_DENSE_LEN"] = v.split(":")[1]
+            os.environ["PPQC_TILE_VARIANT"] = vv
             os.environ["PPQC_TILE_BLOCKS_PER_CU"] = bpc
             os.environ["PPQC_TILE_SHIFT"] = sh
             ctx.reset(); ctx.reset_timings()
