@@ -180,8 +180,8 @@ static int ensure_tiles(ppqc_ctx* c, uint64_t n_tiles) {
     if (cap < n_tiles) cap = n_tiles;
     CHK(grow(&c->head, 0, cap, c->stream));
     CHK(grow(&c->tail, 0, cap, c->stream));
-    CHK(grow(&c->dense.base, 0, cap + 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->dense.base, 0, 64, c->stream));   // both counters; every launch leaves the next one's at zero
+    CHK(grow(&c->dense.base, 0, dense_list_words(cap), c->stream));
+    HIPCHK(hipMemsetAsync(c->dense.base, 0, 128 * 8, c->stream));   // all counters; every launch leaves the next one's at zero
     c->dense.parity = 0;
     c->cap_tiles = cap;
     return PPQC_OK;

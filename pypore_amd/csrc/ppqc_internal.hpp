@@ -76,13 +76,14 @@ struct TableParams {
 };
 
 // ---- launchers (each enqueues on `s`, returns the hipError of the launch) -----------------------------------------
-// Device list of the dense tiles of one launch (8 + one u64 per tile of the batch) with two counters used alternately: launch k
-// counts in counters[k & 1] and its dense kernel puts counters[(k + 1) & 1] back to zero.  launch_tile_kernel flips
+// Device list of the dense tiles of one launch with two sets of counters used alternately: launch k
+// counts in set k & 1 and its dense kernel puts counters[(k + 1) & 1] back to zero.  launch_tile_kernel flips
 // `parity` itself, and only when it has launched a dense kernel (a launch without one -- an A/B knob -- counts nothing).
 struct DenseList {
-    uint64_t* base;   // [0], [1]: the counters; [8 ..]: one entry per tile of the batch
+    uint64_t* base;   // dense_list_words(tiles) u64: 2 x 64 counters, then 64 sub-lists (layout: ppqc_tile.hip, DenseOut)
     int parity;
 };
+uint64_t dense_list_words(uint64_t n_tiles);
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
                               Partial* head, Partial* tail, DenseList& dl, int n_cu, hipStream_t s,
                               bool line_mode = false);

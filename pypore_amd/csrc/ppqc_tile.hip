@@ -488,12 +488,18 @@ __device__ __forceinline__ void process_batch(const uint4 (&vb)[NB], const uint4
 
 // NB spans per batch; NT nontemporal loads; PIPE: two register sets, the next batch is in flight while one is processed.
 // What tile_kernel needs to hand dense tiles over to dense_kernel (see "the boundary strategy is chosen per tile" below).
+// The dense list.  64 sub-lists, each with a counter of its own (one hot counter took 380 us for 30 000 appends): a
+// tile goes to sub-list (tile / 4) % 64, which holds at most dense_sub_cap(n_tiles) entries.  Layout in u64 words:
+//   [0, 64)    counters of the launches with parity 0        [64, 128)  counters of the launches with parity 1
+//   [128 + j * cap, ...)  entries of sub-list j: tile | first read << 32
 // ONE 64-bit kernel argument, because the kernel has no scalar registers to spare (two more and it spills, and any
 // scratch costs it a fifth of its speed):
-//   bits [0,48)  DenseList::base -- [0], [1] the two counters, [8 ..] the entries (tile | first read << 32)
-//   bit  48      which counter this launch counts in
+//   bits [0,48)  DenseList::base
+//   bit  48      the parity of this launch
 //   bits [49,51) 0 = probe every tile, 1 = no tile is dense, 2 = every tile is
 //   bits [51,56) log2 of dense_len: a tile is dense when at least tile_bytes >> that many reads end inside it
+constexpr uint32_t kDenseSubs = 64, kDenseHeader = 2 * kDenseSubs;
+__host__ __device__ inline uint64_t dense_sub_cap(uint64_t n_tiles) { return 4 * (((n_tiles + 3) / 4 + kDenseSubs - 1) / kDenseSubs); }
 typedef uint64_t DenseOut;
 __host__ __device__ inline DenseOut make_dense_out(const uint64_t* base, int parity, uint32_t mode, uint32_t len_log2) {
     return ((uint64_t)(uintptr_t)base & 0xFFFFFFFFFFFFull) | ((uint64_t)(parity & 1) << 48) | ((uint64_t)(mode & 3u) << 49) |
@@ -539,7 +545,9 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
         if (!VECB && dmode == 0) {
             uint64_t T = tile_valid >> ((uint32_t)(dz >> 51) & 31u);
             T = T ? T : 1;
-            probe = sload_u64(c.off, w.r + T < c.R ? w.r + T : c.R);
+            // (fewer than T reads left: not dense -- one stray dense tile, the batch's last, would cost dense_kernel a
+            // whole tile's latency, 40 us, behind this kernel)
+            if (w.r + T <= c.R) probe = sload_u64(c.off, w.r + T);
         }
         w.rs = uniform_u64(c.off[w.r]);
         w.done = false;
@@ -548,9 +556,10 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
         if (!VECB && dmode != 1 && (dmode == 2 || probe <= tile_start + tile_valid)) {   // left to dense_kernel
             if (lane == 0) {
                 uint64_t* base = (uint64_t*)(uintptr_t)(dz & 0xFFFFFFFFFFFFull);
-                const unsigned long long k = atomicAdd((unsigned long long*)(base + ((dz >> 48) & 1ull)), 1ull);
-                if (k < n_tiles) base[8 + k] = t | (w.r << 32);   // a count that starts at zero never gets there: the
-                                                                   // list has one entry per tile
+                const uint64_t j = (t >> 2) & (kDenseSubs - 1), cap = dense_sub_cap(n_tiles);
+                const unsigned long long k = atomicAdd((unsigned long long*)(base + ((dz >> 48) & 1ull) * kDenseSubs + j), 1ull);
+                if (k < cap) base[kDenseHeader + j * cap + k] = t | (w.r << 32);   // a count that starts at zero stays
+                                                                                    // below cap: the tiles of sub-list j
             }
             continue;
         }
@@ -811,33 +820,37 @@ constexpr int kDenseSpans = 4;   // spans per batch of a dense tile (32 VGPRs of
 // dense tile holds at least T = tile_bytes / dense_len read ends and every read ends in one tile, so the list has at most
 // n_reads / T + 1 entries and the grid is sized by that bound: waves beyond the count leave at once (config 2: 15 000
 // waves, 4 us).  counters[parity] is this launch's count; the other counter, last used by the previous launch (complete:
-// stream order) and next by the following one, is put back to zero here.
+// stream order) and next by the following one, is put back to zero here (64 counters per parity: see DenseOut).
 template <bool LINE>
 __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra,
                                                        uint64_t read_base, Partial* __restrict__ head,
                                                        Partial* __restrict__ tail, uint64_t* __restrict__ base,
                                                        int parity) {
-    uint64_t* __restrict__ counters = base;
-    const uint64_t* __restrict__ list = base + 8;
     constexpr int ND = kDenseSpans;
     __shared__ uint64_t lut[256];
     __shared__ uint32_t xs[4][64];
     lut[threadIdx.x] = lut_g[threadIdx.x];
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[parity ^ 1] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < kDenseSubs) base[(uint64_t)(parity ^ 1) * kDenseSubs + threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t n_waves = (uint64_t)gridDim.x * 4;
     const uint64_t kTile = 1ull << b.tile_shift;
     const uint64_t n_tiles = (b.n_bytes + kTile - 1) >> b.tile_shift;
-    uint64_t count = sload_u64(counters, (uint64_t)parity);
-    count = count < n_tiles ? count : n_tiles;        // never more entries than the list holds
+    const uint64_t cap = dense_sub_cap(n_tiles);
+    // lane j: the entries of sub-list j (never more than it holds); their inclusive prefix places a global index
+    const uint64_t cj = base[(uint64_t)parity * kDenseSubs + lane];
+    const uint32_t mine = (uint32_t)(cj < cap ? cj : cap);
+    const uint32_t incl = wave_scan_u32(mine);
+    const uint64_t count = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if ((uint64_t)blockIdx.x * 4 >= count) return;   // whole block: nothing below needs a block-level barrier
     TileCtx c;
     c.read_base = read_base; c.R = b.n_reads; c.off = b.offsets; c.ra = ra; c.head = head; c.lut = lut;
     c.lane = lane; c.lane_off = (uint32_t)lane * kVec; c.xs = &xs[wib][0];
     for (uint64_t i = (uint64_t)blockIdx.x * 4 + wib; i < count; i += n_waves) {
-        const uint64_t e = sload_u64(list, i);
+        const int j = __popcll(__ballot((uint64_t)incl <= i));                   // the sub-list global index i falls in
+        const uint64_t before = j ? (uint32_t)__builtin_amdgcn_readlane((int)incl, j - 1) : 0u;
+        const uint64_t e = sload_u64(base, kDenseHeader + (uint64_t)j * cap + (i - before));
         const uint64_t t = e & 0xFFFFFFFFull;
         if (t >= n_tiles || (e >> 32) >= b.n_reads) continue;   // not an entry of this batch: touch nothing
         const uint64_t tile_start = t << b.tile_shift;
@@ -983,7 +996,7 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
     if (threadIdx.x == 0 && s_max) atomicOr((unsigned long long*)&gate[blockIdx.x & (kGateWords - 1)], (unsigned long long)s_max);
 }
 
-constexpr uint32_t kDenseLen = 1024;   // a tile is dense when its reads average fewer bytes than this
+constexpr uint32_t kDenseLen = 256;    // a tile is dense when its reads average fewer bytes than this (power of two)
 
 template <int NB, bool NT, bool PIPE, bool LINE = false, bool VECB = false>
 static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
@@ -1068,6 +1081,8 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
     if (e == hipSuccess) dl.parity ^= 1;
     return e;
 }
+
+uint64_t dense_list_words(uint64_t n_tiles) { return kDenseHeader + kDenseSubs * dense_sub_cap(n_tiles); }
 
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint64_t thr_fail, double fail_q, uint64_t* csr_errors,
