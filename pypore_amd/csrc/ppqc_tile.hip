@@ -497,19 +497,19 @@ __device__ __forceinline__ void process_batch(const uint4 (&vb)[NB], const uint4
 //   bits [0,48)  DenseList::base
 //   bit  48      the parity of this launch
 //   bits [49,51) 0 = probe every tile, 1 = no tile is dense, 2 = every tile is
-//   bits [51,56) log2 of dense_len: a tile is dense when at least tile_bytes >> that many reads end inside it
+//   bits [51,64) T = tile_bytes / dense_len: a tile is dense when at least T reads end inside it
 constexpr uint32_t kDenseSubs = 64, kDenseHeader = 2 * kDenseSubs;
 __host__ __device__ inline uint64_t dense_sub_cap(uint64_t n_tiles) { return 4 * (((n_tiles + 3) / 4 + kDenseSubs - 1) / kDenseSubs); }
 typedef uint64_t DenseOut;
-__host__ __device__ inline DenseOut make_dense_out(const uint64_t* base, int parity, uint32_t mode, uint32_t len_log2) {
+__host__ __device__ inline DenseOut make_dense_out(const uint64_t* base, int parity, uint32_t mode, uint32_t T) {
     return ((uint64_t)(uintptr_t)base & 0xFFFFFFFFFFFFull) | ((uint64_t)(parity & 1) << 48) | ((uint64_t)(mode & 3u) << 49) |
-           ((uint64_t)(len_log2 & 31u) << 51);
+           ((uint64_t)(T & 8191u) << 51);
 }
 
 template <int NB, bool NT, bool PIPE, bool LINE, bool VECB>
 __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __restrict__ lut_g, const ReadArrays& ra,
                                           uint64_t read_base, Partial* __restrict__ head, Partial* __restrict__ tail,
-                                          uint64_t n_tiles, const DenseOut dz = make_dense_out(nullptr, 0, 1, 10)) {
+                                          uint64_t n_tiles, const DenseOut dz = make_dense_out(nullptr, 0, 1, 64)) {
     __shared__ uint64_t lut[256];
     __shared__ uint32_t xs[4][64];
     lut[threadIdx.x] = lut_g[threadIdx.x];
@@ -543,8 +543,7 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
         const uint32_t dmode = (uint32_t)(dz >> 49) & 3u;
         uint64_t probe = ~0ull;
         if (!VECB && dmode == 0) {
-            uint64_t T = tile_valid >> ((uint32_t)(dz >> 51) & 31u);
-            T = T ? T : 1;
+            const uint64_t T = dz >> 51;   // >= 1
             // (fewer than T reads left: not dense -- one stray dense tile, the batch's last, would cost dense_kernel a
             // whole tile's latency, 40 us, behind this kernel)
             if (w.r + T <= c.R) probe = sload_u64(c.off, w.r + T);
@@ -815,12 +814,53 @@ __device__ __forceinline__ void span_scan(const uint4& vb, const uint4& vq, uint
 
 constexpr int kDenseSpans = 4;   // spans per batch of a dense tile (32 VGPRs of data; the boundary pass needs the rest)
 
+// Two registers of upcoming read ends: w0 lane l = offsets[r0 + 1 + l], w1 lane l = offsets[r0 + 65 + l] (clamped to
+// offsets[R]).  Any 64 consecutive reads from r on, r - r0 < 64, are then at hand without a load; when r passes r0 + 64
+// the registers shift and the load of the new w1 has 64 reads' worth of work to arrive.
+struct Win2 {
+    uint64_t w0, w1, r0;
+    bool ok;
+};
+__device__ __forceinline__ void win_ensure(Win2& W, const TileCtx& c, uint64_t r) {
+    if (!W.ok || r < W.r0 || r - W.r0 >= 128) {
+        uint64_t i0 = r + 1 + (uint64_t)c.lane, i1 = r + 65 + (uint64_t)c.lane;
+        W.w0 = c.off[i0 < c.R ? i0 : c.R];
+        W.w1 = c.off[i1 < c.R ? i1 : c.R];
+        W.r0 = r;
+        W.ok = true;
+    } else if (r - W.r0 >= 64) {
+        W.w0 = W.w1;
+        W.r0 += 64;
+        const uint64_t i1 = W.r0 + 65 + (uint64_t)c.lane;
+        W.w1 = c.off[i1 < c.R ? i1 : c.R];
+    }
+}
+// lane j: the end of read r + j (r - W.r0 < 64)
+__device__ __forceinline__ uint64_t win_ends(const Win2& W, uint64_t r, int lane) {
+    const int idx = (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r - W.r0)) + lane;   // 0 .. 126
+    const uint64_t a = __shfl((unsigned long long)W.w0, idx & 63), b = __shfl((unsigned long long)W.w1, idx & 63);
+    return idx < 64 ? a : b;
+}
+
 // The dense tiles of a batch, from the list tile_kernel left: entry = tile | first read << 32.  One tile per wave, like
 // tile_kernel (persistent grids lose to the hardware dispatcher here as there); the host does not know the count, but a
 // dense tile holds at least T = tile_bytes / dense_len read ends and every read ends in one tile, so the list has at most
 // n_reads / T + 1 entries and the grid is sized by that bound: waves beyond the count leave at once (config 2: 15 000
 // waves, 4 us).  counters[parity] is this launch's count; the other counter, last used by the previous launch (complete:
 // stream order) and next by the following one, is put back to zero here (64 counters per parity: see DenseOut).
+//
+// ENTRY SPACE.  The read ends inside a span are taken in read order, one lane each: lane j holds the j-th end p_j of the
+// span (from the window registers), the vector it cuts v_j = (p_j - span_start) / 16 and the offset x_j inside it.  A
+// batch of four spans goes through four phases.  (1) Per span: the entries; each fetches the 32 bytes of data lane v_j
+// (eight ds_bpermute) into the batch's gather list in LDS.  (2) ONE masked pass over the gathered vectors, 64 entries at
+// a time, leaves every entry's prefix sums pre_j (sums of the first x_j bytes) in its slot.  (3) Per span: full sums per
+// data lane, their exclusive wave scan E (u32 pieces, six v_add_u32_dpp each); entry j then knows the sums from the span's
+// start to its end, Q_j = E[v_j] + pre_j, and the read that ends there owns Q_j - Q_(j-1) -- the first of the span
+// Q_0 + S, S being the wave-uniform carry of the open read -- and lane j stores the record of read r + j: consecutive
+// lanes, consecutive records.  What lies behind the last end, total - Q_last, is the new carry.  Ends that share a
+// vector, empty reads, ends on a span's edge are all just entries; only a span with 64 or more ends (reads of fewer
+// than 16 bytes on average) goes span by span through span_scan.  The error sums are recombined to 64 bits before any
+// subtraction (the pieces of a difference are not field by field non-negative); the packed counters subtract as they are.
 template <bool LINE>
 __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra,
                                                        uint64_t read_base, Partial* __restrict__ head,
@@ -829,6 +869,9 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
     constexpr int ND = kDenseSpans;
     __shared__ uint64_t lut[256];
     __shared__ uint32_t xs[4][64];
+    __shared__ uint4 cutb[4][64 * ND];      // gathered cut vectors (bases); the prefix sums come back in the same slots
+    __shared__ uint4 cutq[4][64 * ND];      // (qualities)
+    __shared__ uint32_t cutx[4][64 * ND];   // their cut offsets
     lut[threadIdx.x] = lut_g[threadIdx.x];
     if (blockIdx.x == 0 && threadIdx.x < kDenseSubs) base[(uint64_t)(parity ^ 1) * kDenseSubs + threadIdx.x] = 0;
     __syncthreads();
@@ -847,6 +890,9 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
     TileCtx c;
     c.read_base = read_base; c.R = b.n_reads; c.off = b.offsets; c.ra = ra; c.head = head; c.lut = lut;
     c.lane = lane; c.lane_off = (uint32_t)lane * kVec; c.xs = &xs[wib][0];
+    uint4* __restrict__ gb = &cutb[wib][0];
+    uint4* __restrict__ gq = &cutq[wib][0];
+    uint32_t* __restrict__ gx = &cutx[wib][0];
     for (uint64_t i = (uint64_t)blockIdx.x * 4 + wib; i < count; i += n_waves) {
         const int j = __popcll(__ballot((uint64_t)incl <= i));                   // the sub-list global index i falls in
         const uint64_t before = j ? (uint32_t)__builtin_amdgcn_readlane((int)incl, j - 1) : 0u;
@@ -869,21 +915,112 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
         w.done = false;
         w.win = 0; w.win_r0 = 0; w.win_ok = false;
         w.re2 = 0;
-        w.re = read_end(w, c, w.r);
+        Win2 W;
+        W.ok = false;
+        win_ensure(W, c, w.r);
+        w.re = readlane_u64(win_ends(W, w.r, lane), 0);
         w.re_rel = rel_end(w.re, tile_start);
         Acc acc{0, 0, 0, 0};
         bool dirty = false;
         Carry S{0, 0, 0, 0, 0};
         for (uint32_t s0 = 0; s0 < n_spans && !w.done; s0 += ND) {
             if (s0) load_part<0, ND, ND, true, LINE>(vb, vq, pb, pq, s0, c.lane_off, last_vec);
+            // ---- (1) the entries of the batch's spans, their vectors gathered in LDS
+            const uint64_t r0 = w.r, rs0 = w.rs, re0 = w.re;
+            uint32_t relk[ND], rdel[ND], nk[ND];
+            uint32_t nproc = 0, n_cuts = 0;
+            bool ok = true;
 #pragma unroll
             for (int k = 0; k < ND; ++k) {
-                if (s0 + k >= n_spans || w.done) break;
-                const uint32_t span_end_rel = (s0 + k + 1) * kSpan;
-                if (w.re_rel >= span_end_rel) {   // no read ends strictly inside the span
+                relk[k] = 0; rdel[k] = 0; nk[k] = 0;
+                if (s0 + k >= n_spans || w.done || !ok) continue;
+                nproc = k + 1;
+                rdel[k] = (uint32_t)(w.r - r0);
+                const uint64_t span_start = tile_start + (uint64_t)(s0 + k) * kSpan, span_end = span_start + kSpan;
+                if (w.re >= span_end) continue;   // no end inside: a fast span
+                win_ensure(W, c, w.r);
+                const uint64_t ends = win_ends(W, w.r, lane);
+                // (a malformed device CSR may hold ends out of order: only the leading run of ends inside the span counts,
+                // so every index stays in range; finalize_reads reports the batch)
+                const bool in = w.r + (uint64_t)lane < c.R && ends < span_end && ends >= span_start;
+                const uint64_t nin = ~__ballot(in);
+                const uint32_t n = nin ? (uint32_t)__builtin_ctzll(nin) : 64u;
+                if (n == 0 || n >= 64) { ok = false; continue; }   // 64 ends in one span: span by span (below)
+                const uint32_t rel = (uint32_t)(ends - span_start) & (kSpan - 1);
+                const int v = (int)(rel >> 4);
+                const uint4 eb = make_uint4((uint32_t)__shfl((int)vb[k].x, v), (uint32_t)__shfl((int)vb[k].y, v),
+                                            (uint32_t)__shfl((int)vb[k].z, v), (uint32_t)__shfl((int)vb[k].w, v));
+                uint4 eq = eb;
+                if (!LINE)
+                    eq = make_uint4((uint32_t)__shfl((int)vq[k].x, v), (uint32_t)__shfl((int)vq[k].y, v),
+                                    (uint32_t)__shfl((int)vq[k].z, v), (uint32_t)__shfl((int)vq[k].w, v));
+                if ((uint32_t)lane < n) {
+                    gb[n_cuts + lane] = eb;
+                    gq[n_cuts + lane] = eq;
+                    gx[n_cuts + lane] = rel & 15u;
+                }
+                relk[k] = rel;
+                nk[k] = n;
+                n_cuts += n;
+                w.rs = readlane_u64(ends, (int)n - 1);
+                w.r += n;
+                w.done = w.r >= c.R;
+                if (!w.done) {
+                    w.re = readlane_u64(ends, (int)n);   // n < 64: the end of read w.r is in the same register
+                    w.re_rel = rel_end(w.re, tile_start);
+                }
+            }
+            if (!ok) {
+                // a span with 64 or more ends somewhere in the batch: span by span, from the state the batch began with
+                w.r = r0; w.rs = rs0; w.re = re0; w.done = false;
+                w.re_rel = rel_end(w.re, tile_start);
+                w.win_ok = false;
+#pragma unroll
+                for (int k = 0; k < ND; ++k) {
+                    if (s0 + k >= n_spans || w.done) break;
+                    const uint32_t span_rel = (s0 + k) * kSpan, span_end_rel = span_rel + kSpan;
+                    if (w.re_rel <= span_rel && span_rel != 0) {
+                        // (an end left on this span's edge by the batch before: the read owns nothing here)
+                        flush_read_c(acc, dirty, S, w, c);
+                        walk_advance<true>(w, c);
+                        if (w.done) break;
+                    }
+                    if (w.re_rel >= span_end_rel) {
+                        Acc tot = vec_sums(vb[k], LINE ? vb[k] : vq[k], c.lut);
+                        acc_add(acc, tot);
+                        dirty = true;
+                        if (w.re_rel == span_end_rel) {
+                            flush_read_c(acc, dirty, S, w, c);
+                            walk_advance<true>(w, c);
+                        }
+                    } else {
+                        span_scan(vb[k], LINE ? vb[k] : vq[k], span_rel, w, acc, dirty, S, c);
+                    }
+                }
+                W.ok = false;
+                continue;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- (2) one masked pass over the gathered vectors (64 at a time): slot = {gcs | n << 16, qb, err}
+            for (uint32_t g0 = 0; g0 < n_cuts; g0 += 64) {
+                const uint32_t gi = g0 + (uint32_t)lane < n_cuts ? g0 + (uint32_t)lane : n_cuts - 1;
+                const Acc pre = vec_prefix(gb[gi], gq[gi], (int)gx[gi], c.lut);
+                __builtin_amdgcn_wave_barrier();
+                if (g0 + (uint32_t)lane < n_cuts)
+                    gb[gi] = make_uint4(pre.gcs | (pre.n << 16), pre.qb, (uint32_t)pre.err, (uint32_t)(pre.err >> 32));
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- (3) per span: full sums, exclusive scan, the entries' records
+            uint32_t cbase = 0;
+            bool head_pending = rs0 < tile_start;   // the open read began in an earlier tile: its end is the head partial
+#pragma unroll
+            for (int k = 0; k < ND; ++k) {
+                if ((uint32_t)k >= nproc) break;
+                const uint32_t n = nk[k];
+                if (!n) {
                     Acc tot;
                     if (LINE) {
-                        const uint32_t ty = (uint32_t)w.r & 3u;
+                        const uint32_t ty = (uint32_t)(r0 + rdel[k]) & 3u;
                         if (ty == 1u) tot = vec_sums_bases(vb[k]);
                         else if (ty == 3u) tot = vec_sums_quals(vb[k], c.lut);
                         else tot = Acc{0, 0, 0, 0};
@@ -892,18 +1029,67 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
                     }
                     acc_add(acc, tot);
                     dirty = true;
-                    if (w.re_rel == span_end_rel) {
-                        flush_read_c(acc, dirty, S, w, c);
-                        walk_advance<true>(w, c);
-                    }
-                } else {
-                    span_scan(vb[k], LINE ? vb[k] : vq[k], (s0 + k) * kSpan, w, acc, dirty, S, c);
+                    continue;
                 }
+                const Acc tot = vec_sums(vb[k], LINE ? vb[k] : vq[k], c.lut);
+                if (dirty) {   // fast spans since the last end: fold the per-lane sums into the carry
+                    Carry Z = S;
+                    const uint32_t G = wave_sum_u32(acc.gcs), N = wave_sum_u32(acc.n), Q = wave_sum_u32(acc.qb);
+                    const uint32_t E0 = wave_sum_u32((uint32_t)acc.err & 0x1FFFFFu);
+                    const uint32_t E1 = wave_sum_u32((uint32_t)(acc.err >> 21) & 0x1FFFFFu);
+                    const uint32_t E2 = wave_sum_u32((uint32_t)(acc.err >> 42));
+                    Z.gcs += G; Z.n += N; Z.qb += Q;
+                    Z.lo += (uint64_t)E0 + ((uint64_t)E1 << 21);
+                    Z.hi += (uint64_t)E2 << 10;
+                    S = Z;
+                    acc = Acc{0, 0, 0, 0};
+                    dirty = false;
+                }
+                // data lanes: inclusive scan of the full sums, then exclusive; the error sum back in 64 bits
+                const Pieces a = to_pieces(tot);
+                const Pieces P{wave_scan_u32(a.c1), wave_scan_u32(a.c2), wave_scan_u32(a.e0), wave_scan_u32(a.e1)};
+                const uint32_t Ec1 = P.c1 - a.c1, Eqb = (P.c2 - a.c2) & 0x3FFFFu;
+                const uint64_t Eerr = pieces_err(P) - tot.err;
+                const uint32_t Tc1 = (uint32_t)__builtin_amdgcn_readlane((int)P.c1, 63);
+                const uint32_t Tqb = (uint32_t)__builtin_amdgcn_readlane((int)P.c2, 63) & 0x3FFFFu;
+                const uint64_t Terr = readlane_u64(pieces_err(P), 63);
+                // entry lanes: sums from the span's start to the entry's end
+                const int v = (int)(relk[k] >> 4);
+                const uint4 pv = gb[cbase + ((uint32_t)lane < n ? (uint32_t)lane : 0u)];
+                cbase += n;
+                const uint32_t Qc1 = (uint32_t)__shfl((int)Ec1, v) + pv.x;
+                const uint32_t Qqb = (uint32_t)__shfl((int)Eqb, v) + pv.y;
+                const uint64_t Qerr = __shfl((unsigned long long)Eerr, v) + ((uint64_t)pv.z | ((uint64_t)pv.w << 32));
+                const uint32_t pc1 = (uint32_t)__shfl_up((int)Qc1, 1), pqb = (uint32_t)__shfl_up((int)Qqb, 1);
+                const uint64_t perr = __shfl_up((unsigned long long)Qerr, 1);
+                if ((uint32_t)lane < n) {
+                    const bool first = lane == 0;
+                    const uint32_t oc1 = Qc1 - (first ? 0u : pc1);
+                    uint32_t gcs = oc1 & 0xFFFFu, nn = oc1 >> 16, qb = Qqb - (first ? 0u : pqb);
+                    uint64_t lo = Qerr - (first ? 0ull : perr), hi = 0;
+                    if (first) { gcs += S.gcs; nn += S.n; qb += S.qb; lo += S.lo; hi = S.hi; }
+                    const uint64_t ri = c.read_base + r0 + rdel[k] + (uint32_t)lane;
+                    const bool to_head = first && head_pending;
+                    Partial* p = &c.head[c.t];
+                    *(to_head ? &p->cnt : &c.ra.rec_cnt[ri]) = pack_cnt(gcs, nn, qb);
+                    *(to_head ? &p->hi : &c.ra.rec_hi[ri]) = hi;
+                    *(to_head ? &p->lo : &c.ra.rec_lo[ri]) = lo;
+                }
+                // what lies behind the last end opens the next read
+                const uint32_t Lc1 = Tc1 - (uint32_t)__builtin_amdgcn_readlane((int)Qc1, (int)n - 1);
+                const uint32_t Lqb = Tqb - (uint32_t)__builtin_amdgcn_readlane((int)Qqb, (int)n - 1);
+                const uint64_t Lerr = Terr - readlane_u64(Qerr, (int)n - 1);
+                S = Carry{Lc1 & 0xFFFFu, Lc1 >> 16, Lqb, 0, Lerr};
+                head_pending = false;
             }
         }
-        if (!w.done && w.rs < tile_start + kTile && w.re > tile_start + kTile) {
-            Partial* p = w.rs >= tile_start ? &tail[t] : &head[t];
-            flush_c(acc, dirty, S, lane, &p->cnt, &p->hi, &p->lo);
+        if (!w.done) {
+            if (w.re == tile_start + tile_valid) {
+                flush_read_c(acc, dirty, S, w, c);     // the read ends with the tile: complete, or the head partial
+            } else if (w.rs < tile_start + kTile && w.re > tile_start + kTile) {
+                Partial* p = w.rs >= tile_start ? &tail[t] : &head[t];
+                flush_c(acc, dirty, S, lane, &p->cnt, &p->hi, &p->lo);
+            }
         }
     }
 }
@@ -996,7 +1182,7 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
     if (threadIdx.x == 0 && s_max) atomicOr((unsigned long long*)&gate[blockIdx.x & (kGateWords - 1)], (unsigned long long)s_max);
 }
 
-constexpr uint32_t kDenseLen = 256;    // a tile is dense when its reads average fewer bytes than this (power of two)
+constexpr uint32_t kDenseLen = 768;    // a tile is dense when its reads average fewer bytes than this
 
 template <int NB, bool NT, bool PIPE, bool LINE = false, bool VECB = false>
 static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
@@ -1037,16 +1223,17 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
     const int variant = v ? atoi(v) : 0;
     uint32_t mode = dm ? (atoi(dm) ? 2u : 1u) : 0u;
     if (!dl.base || variant != 0) mode = 1;
-    uint32_t len_log2 = 0;
-    for (uint32_t d = dlen ? (uint32_t)atoi(dlen) : kDenseLen; d > 1; d >>= 1) ++len_log2;   // a power of two
-    if (len_log2 < 4) len_log2 = 4;
-    DenseOut dz = make_dense_out(dl.base, dl.parity, mode, len_log2);
+    uint32_t dense_len = dlen ? (uint32_t)atoi(dlen) : kDenseLen;
+    if (dense_len < 16) dense_len = 16;
+    uint32_t T = (uint32_t)((1ull << b.tile_shift) / dense_len);
+    T = T < 1 ? 1 : (T > 8191 ? 8191 : T);
+    DenseOut dz = make_dense_out(dl.base, dl.parity, mode, T);
     hipError_t e;
     if (line_mode) {
         const char* lv = getenv("PPQC_LINE_VECB");
         if (lv && atoi(lv) != 0) {
             mode = 1;
-            dz = make_dense_out(dl.base, dl.parity, mode, len_log2);
+            dz = make_dense_out(dl.base, dl.parity, mode, T);
             e = launch_tile_variant<8, true, false, true, true>(b, lut_dev, ra, read_base, head, tail, n_cu, 0, dz, s);
         } else {
             e = launch_tile_variant<8, true, false, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, 0, dz, s);
@@ -1063,8 +1250,6 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
     const uint64_t n_tiles = (b.n_bytes + (1ull << b.tile_shift) - 1) >> b.tile_shift;
     uint64_t bound = n_tiles;
     if (mode == 0) {
-        uint64_t T = (1ull << b.tile_shift) >> len_log2;
-        T = T ? T : 1;
         const uint64_t most = b.n_reads / T + 1;
         if (most < bound) bound = most;
     }
