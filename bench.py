@@ -150,7 +150,7 @@ def workload_shape(a):
 
 def workload_text(a, R, n_bytes):
     if a.workload == "config4adv":
-        shape = "99.95 %% reads of 200 b + 100 reads of 2 Mb scattered through the batch"
+        shape = "99.95 % reads of 200 b + 100 reads of 2 Mb scattered through the batch"
     else:
         shape = "lognormal(mu=%.4f, sigma=%.4f) clipped [1, 2e6]" % (a.mu, a.sigma)
     return "%s: %d reads/GPU, %s, %.2f Gbases + quals per GPU, %d channels, %d hourly bins, tables + radix-sort N50 " \

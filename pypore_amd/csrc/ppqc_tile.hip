@@ -861,7 +861,11 @@ __device__ __forceinline__ uint64_t win_ends(const Win2& W, uint64_t r, int lane
 // vector, empty reads, ends on a span's edge are all just entries; only a span with 64 or more ends (reads of fewer
 // than 16 bytes on average) goes span by span through span_scan.  The error sums are recombined to 64 bits before any
 // subtraction (the pieces of a difference are not field by field non-negative); the packed counters subtract as they are.
-template <bool LINE>
+//
+// ALL: a batch whose reads average fewer bytes than the density threshold is dense nearly everywhere, and tile_kernel's
+// pass over it would do nothing but probe and append (0.21 of 1.40 ms at a mean of 500 B).  Such a batch is launched as
+// dense_kernel<.., true> alone: one wave per tile of the batch, no list, the first read by the same 64-ary search.
+template <bool LINE, bool ALL>
 __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra,
                                                        uint64_t read_base, Partial* __restrict__ head,
                                                        Partial* __restrict__ tail, uint64_t* __restrict__ base,
@@ -873,7 +877,7 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
     __shared__ uint4 cutq[4][64 * ND];      // (qualities)
     __shared__ uint32_t cutx[4][64 * ND];   // their cut offsets
     lut[threadIdx.x] = lut_g[threadIdx.x];
-    if (blockIdx.x == 0 && threadIdx.x < kDenseSubs) base[(uint64_t)(parity ^ 1) * kDenseSubs + threadIdx.x] = 0;
+    if (!ALL && blockIdx.x == 0 && threadIdx.x < kDenseSubs) base[(uint64_t)(parity ^ 1) * kDenseSubs + threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -881,11 +885,15 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
     const uint64_t kTile = 1ull << b.tile_shift;
     const uint64_t n_tiles = (b.n_bytes + kTile - 1) >> b.tile_shift;
     const uint64_t cap = dense_sub_cap(n_tiles);
-    // lane j: the entries of sub-list j (never more than it holds); their inclusive prefix places a global index
-    const uint64_t cj = base[(uint64_t)parity * kDenseSubs + lane];
-    const uint32_t mine = (uint32_t)(cj < cap ? cj : cap);
-    const uint32_t incl = wave_scan_u32(mine);
-    const uint64_t count = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t incl = 0;
+    uint64_t count = n_tiles;
+    if (!ALL) {
+        // lane j: the entries of sub-list j (never more than it holds); their inclusive prefix places a global index
+        const uint64_t cj = base[(uint64_t)parity * kDenseSubs + lane];
+        const uint32_t mine = (uint32_t)(cj < cap ? cj : cap);
+        incl = wave_scan_u32(mine);
+        count = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
     if ((uint64_t)blockIdx.x * 4 >= count) return;   // whole block: nothing below needs a block-level barrier
     TileCtx c;
     c.read_base = read_base; c.R = b.n_reads; c.off = b.offsets; c.ra = ra; c.head = head; c.lut = lut;
@@ -894,11 +902,14 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
     uint4* __restrict__ gq = &cutq[wib][0];
     uint32_t* __restrict__ gx = &cutx[wib][0];
     for (uint64_t i = (uint64_t)blockIdx.x * 4 + wib; i < count; i += n_waves) {
-        const int j = __popcll(__ballot((uint64_t)incl <= i));                   // the sub-list global index i falls in
-        const uint64_t before = j ? (uint32_t)__builtin_amdgcn_readlane((int)incl, j - 1) : 0u;
-        const uint64_t e = sload_u64(base, kDenseHeader + (uint64_t)j * cap + (i - before));
+        uint64_t e = i;
+        if (!ALL) {
+            const int j = __popcll(__ballot((uint64_t)incl <= i));               // the sub-list global index i falls in
+            const uint64_t before = j ? (uint32_t)__builtin_amdgcn_readlane((int)incl, j - 1) : 0u;
+            e = sload_u64(base, kDenseHeader + (uint64_t)j * cap + (i - before));
+        }
         const uint64_t t = e & 0xFFFFFFFFull;
-        if (t >= n_tiles || (e >> 32) >= b.n_reads) continue;   // not an entry of this batch: touch nothing
+        if (t >= n_tiles || (!ALL && (e >> 32) >= b.n_reads)) continue;   // not an entry of this batch: touch nothing
         const uint64_t tile_start = t << b.tile_shift;
         const uint64_t remain = b.n_bytes - tile_start;
         const uint32_t tile_valid = remain < kTile ? (uint32_t)remain : (uint32_t)kTile;
@@ -910,7 +921,7 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
         uint4 vb[ND], vq[ND];
         load_part<0, ND, ND, true, LINE>(vb, vq, pb, pq, 0, c.lane_off, last_vec);
         Walk w;
-        w.r = e >> 32;
+        w.r = ALL ? find_read(c.off, c.R, tile_start, lane) : e >> 32;
         w.rs = uniform_u64(c.off[w.r]);
         w.done = false;
         w.win = 0; w.win_r0 = 0; w.win_ok = false;
@@ -1183,6 +1194,14 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
 }
 
 constexpr uint32_t kDenseLen = 768;    // a tile is dense when its reads average fewer bytes than this
+// dense_kernel alone (no tile_kernel pass, no list) for a batch whose reads average fewer than kDenseAllLen bytes: at a
+// mean of 1 kb it is as fast as the pair (3870 against 3840 GB/s), below that faster (mean 500 B: 3525 against 3070, 150 B:
+// 3330 against 3030), above it slower (2.5 kb: 4540 against 5630: its sparse spans run at 3 waves per SIMD with 8 loads
+// in flight).  A small batch pays the pair's second launch and the wait between the two (about 15 us) whatever it holds,
+// which is what dense_kernel loses on 190 MB of sparse tiles: below kSmallBatchBytes the bound is kDenseAllLenSmall
+// (the adversarial mix of BASELINE config 4, 240 MB, mean 1.2 kb: 0.126 against 0.141 ms).
+constexpr uint32_t kDenseAllLen = 1024, kDenseAllLenSmall = 2048;
+constexpr uint64_t kSmallBatchBytes = 256ull << 20;
 
 template <int NB, bool NT, bool PIPE, bool LINE = false, bool VECB = false>
 static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
@@ -1229,6 +1248,22 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
     T = T < 1 ? 1 : (T > 8191 ? 8191 : T);
     DenseOut dz = make_dense_out(dl.base, dl.parity, mode, T);
     hipError_t e;
+    // a batch that is dense on average: dense_kernel alone, over every tile (PPQC_TILE_ALL = 0 | 1 overrides the choice)
+    const char* da = getenv("PPQC_TILE_ALL");
+    const bool all = da ? atoi(da) != 0
+                        : (mode == 0 && b.n_bytes / b.n_reads < (b.n_bytes < kSmallBatchBytes ? kDenseAllLenSmall : kDenseAllLen));
+    if (all && variant == 0 && !(line_mode && getenv("PPQC_LINE_VECB") && atoi(getenv("PPQC_LINE_VECB")) != 0)) {
+        const uint64_t n_tiles = (b.n_bytes + (1ull << b.tile_shift) - 1) >> b.tile_shift;
+        uint64_t blocks = (n_tiles + 3) / 4;
+        if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+        if (line_mode)
+            hipLaunchKernelGGL((dense_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base,
+                               head, tail, dl.base, dl.parity);
+        else
+            hipLaunchKernelGGL((dense_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base,
+                               head, tail, dl.base, dl.parity);
+        return hipGetLastError();
+    }
     if (line_mode) {
         const char* lv = getenv("PPQC_LINE_VECB");
         if (lv && atoi(lv) != 0) {
@@ -1256,10 +1291,10 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
     uint64_t blocks = (bound + 3) / 4;
     if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
     if (line_mode)
-        hipLaunchKernelGGL(dense_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head, tail,
+        hipLaunchKernelGGL((dense_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head, tail,
                            dl.base, dl.parity);
     else
-        hipLaunchKernelGGL(dense_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head,
+        hipLaunchKernelGGL((dense_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head,
                            tail, dl.base, dl.parity);
     e = hipGetLastError();
     // the counters change roles only when a dense_kernel has run: it is what leaves the other counter at zero

@@ -52,14 +52,17 @@ for case in range(n_cases):
     t = np.full(n, 1_528_000_000, np.int64)
     want = co.per_read(bases, quals, off, nthreads=8)
     werr = [int(e) for e in want["err"]]
-    # kernel configurations: the shipped pair of kernels (per-tile probe) at two thresholds, every tile forced sparse
-    # (tile_kernel alone), every tile forced dense (dense_kernel alone), and the older one-kernel VECB instantiation
-    for vecb in ("auto", "auto64", "sparse", "dense", "vecb108"):
+    # kernel configurations: what ships (dense_kernel alone for a batch that is dense on average, else the pair with its
+    # per-tile probe), the pair at a second threshold, every tile forced sparse (tile_kernel alone), every tile forced
+    # onto the dense list, dense_kernel alone over every tile, and the older one-kernel VECB instantiation
+    for vecb in ("auto", "auto64", "sparse", "dense", "all", "vecb108"):
         for shift in ("16", "13", "12"):
-            for k in ("PPQC_TILE_VECB", "PPQC_TILE_VARIANT", "PPQC_TILE_DENSE", "PPQC_TILE_DENSE_LEN"):
+            for k in ("PPQC_TILE_VECB", "PPQC_TILE_VARIANT", "PPQC_TILE_DENSE", "PPQC_TILE_DENSE_LEN", "PPQC_TILE_ALL"):
                 os.environ.pop(k, None)
             if vecb == "sparse": os.environ["PPQC_TILE_DENSE"] = "0"
             if vecb == "dense": os.environ["PPQC_TILE_DENSE"] = "1"
+            if vecb == "all": os.environ["PPQC_TILE_ALL"] = "1"      # dense_kernel alone over every tile
+            if vecb in ("auto64", "sparse", "dense"): os.environ["PPQC_TILE_ALL"] = "0"   # the pair, whatever the mean
             if vecb == "auto64": os.environ["PPQC_TILE_DENSE_LEN"] = "64"
             if vecb == "vecb108": os.environ["PPQC_TILE_VARIANT"] = "108"
             os.environ["PPQC_TILE_SHIFT"] = shift
@@ -75,5 +78,5 @@ for case in range(n_cases):
                 print("MISMATCH case %d regime %d vecb %s shift %s field %s" % (case, regime, vecb, shift, k), flush=True)
     if case % 10 == 9:
         print("case %d done, %.0f s, %d mismatches" % (case, time.time() - t0, bad), flush=True)
-print("fuzz: %d cases x 15 kernel configurations, %d mismatches" % (n_cases, bad))
+print("fuzz: %d cases x 18 kernel configurations, %d mismatches" % (n_cases, bad))
 sys.exit(1 if bad else 0)

@@ -39,13 +39,16 @@ for rnd in range(rounds + 1):
     for v in variants:
         for bpc, sh in [(x, y) for x in bpcs for y in shifts]:
             # "0" = the shipped pair of kernels (per-tile probe); "0s" / "0d" force every tile sparse / dense;
-            # "0:LEN" sets the density threshold; "108" = the older one-kernel VECB instantiation
+            # "0a" / "0p": dense_kernel alone / always the pair; "0:LEN" sets the density threshold; "108" = the older one-kernel VECB instantiation
             os.environ.pop("PPQC_TILE_DENSE", None); os.environ.pop("PPQC_TILE_DENSE_LEN", None)
+            os.environ.pop("PPQC_TILE_ALL", None)
             vv = v
             if v[0] == "0":
                 vv = "0"
                 if v.endswith("d"): os.environ["PPQC_TILE_DENSE"] = "1"
                 if v.endswith("s"): os.environ["PPQC_TILE_DENSE"] = "0"
+                if v.endswith("a"): os.environ["PPQC_TILE_ALL"] = "1"    # dense_kernel alone over every tile
+                if v.endswith("p"): os.environ["PPQC_TILE_ALL"] = "0"    # always the pair, whatever the mean
                 if ":" in v: os.environ["PPQC_TILE_DENSE_LEN"] = v.split(":")[1]
             os.environ["PPQC_TILE_VARIANT"] = vv
             os.environ["PPQC_TILE_BLOCKS_PER_CU"] = bpc
