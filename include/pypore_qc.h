@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PPQC_ABI_VERSION 5
+#define PPQC_ABI_VERSION 6
 
 enum {
     PPQC_OK = 0,
@@ -299,6 +299,28 @@ int ppqc_n50_select_pick(ppqc_ctx* ctx, int round);
 int ppqc_index_early(ppqc_ctx* ctx, int* out);
 int ppqc_stream_wait_index(ppqc_ctx* ctx, void* stream);
 int ppqc_n50_select_early(ppqc_ctx* ctx, int round, int phase, void* stream);
+
+/* time_mode 1 when the reads of a channel are spread over several GPUs (the reference's workers each hold one channel's
+ * reads, lib/seq_routines.py:909-915, and apply the hour rule of lib/fast5_reader.py:117-126 to them in start-time
+ * order).  The rule needs three small per-channel tables the ranks agree on, not the reads themselves:
+ *   ppqc_finalize_extremes; [all-reduce MAX of max_buf | min_buf]
+ *   ppqc_mode1_dist_phase(ctx, 0)   first[ch] = ~(earliest start time of the channel)        -> all-reduce MAX of `first`
+ *   ppqc_mode1_dist_phase(ctx, 1)   ties[ch] = reads starting at that time; per channel and day (PPQC_MODE1_DAYS days
+ *                                   from the day before the reference time) the latest and the complemented earliest
+ *                                   start time of the other reads   -> all-reduce SUM of `ties`, all-reduce MAX of `days`
+ *   ppqc_mode1_dist_phase(ctx, 2)   per channel the start time from which reads are bumped by 24, then every read's hour
+ *   ppqc_finalize_tables            (finds the hours done and does not sort)
+ * With one rank (no collectives) the hours are those of the sort-based path of ppqc_finalize_tables.  Reads outside the
+ * day window are counted in ties[n_channels] (merged like the rest): ppqc_fetch_tables then fails with PPQC_E_RANGE on
+ * every rank.  ppqc_mode1_dist_view allocates the tables on first use; all three are int64 device arrays. */
+#define PPQC_MODE1_DAYS 64
+typedef struct ppqc_mode1_tables {
+    void* first; uint64_t n_first;   /* n_channels */
+    void* ties;  uint64_t n_ties;    /* n_channels + 1 */
+    void* days;  uint64_t n_days;    /* 2 * n_channels * PPQC_MODE1_DAYS */
+} ppqc_mode1_tables;
+int ppqc_mode1_dist_view(ppqc_ctx* ctx, ppqc_mode1_tables* out);
+int ppqc_mode1_dist_phase(ppqc_ctx* ctx, int phase);
 
 /* Enqueue all further work of the context on a caller-owned HIP stream (use_external != 0; `stream` is a hipStream_t,
  * 0 = the null stream) so that it is stream-ordered with the caller's own kernels and RCCL collectives without host

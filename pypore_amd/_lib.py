@@ -31,6 +31,7 @@ SYMBOLS = (
     "ppqc_finalize_tables", "ppqc_finalize_n50", "ppqc_fetch_tables", "ppqc_fetch_tables_view", "ppqc_finalize", "ppqc_finalize_view", "ppqc_device_tables_view",
     "ppqc_timings", "ppqc_reset_timings", "ppqc_sort_u32_device", "ppqc_sort_u32_device_static", "ppqc_synth_fill_device", "ppqc_fastq_scan", "ppqc_fastq_pack",
     "ppqc_submit_fastq", "ppqc_submit_fastq_device", "ppqc_input_errors", "ppqc_time_range", "ppqc_set_ref_time", "ppqc_n50_select_hist", "ppqc_n50_select_pick", "ppqc_index_early", "ppqc_stream_wait_index", "ppqc_n50_select_early", "ppqc_set_stream",
+    "ppqc_mode1_dist_view", "ppqc_mode1_dist_phase",
 )
 
 
@@ -78,6 +79,11 @@ class DeviceTables(C.Structure):
                 ("off_totals", "off_len_log2", "off_len_lin", "off_q_hist", "off_gc_hist", "off_hour_reads",
                  "off_hour_bases", "off_chan_reads", "off_chan_bases", "off_chan_fail", "off_cmh_reads",
                  "off_cmh_bases")] + [("sel_buf", C.c_void_p), ("n_sel", C.c_uint64)]
+
+
+class Mode1Tables(C.Structure):
+    _fields_ = [("first", C.c_void_p), ("n_first", C.c_uint64), ("ties", C.c_void_p), ("n_ties", C.c_uint64),
+                ("days", C.c_void_p), ("n_days", C.c_uint64)]
 
 
 class Timing(C.Structure):
@@ -144,6 +150,7 @@ def load():
         "ppqc_index_early": [P, C.POINTER(C.c_int)], "ppqc_stream_wait_index": [P, C.c_void_p],
         "ppqc_n50_select_early": [P, C.c_int, C.c_int, C.c_void_p],
         "ppqc_set_stream": [P, P, C.c_int],
+        "ppqc_mode1_dist_view": [P, C.POINTER(Mode1Tables)], "ppqc_mode1_dist_phase": [P, C.c_int],
         "ppqc_fastq_scan": [P, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "ppqc_fastq_pack": [P, C.c_uint64, C.c_uint64, P, P, P, P, P, P, P, C.POINTER(C.c_uint64)],
     }

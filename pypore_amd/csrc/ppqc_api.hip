@@ -126,6 +126,8 @@ struct ppqc_ctx {
     hipEvent_t ev_pre = nullptr;   // behind the newest of those kernels (auxiliary stream)
     hipEvent_t ev_clean = nullptr; // behind the clear of the result buffer (ppqc_reset / ppqc_create, main stream)
     uint64_t* maxlen_host = nullptr;   // a few pinned scratch words (line count of the GPU tokenizer)
+    uint64_t* m1 = nullptr;            // time_mode 1 across ranks: [first | ties | days] (ppqc_mode1_dist_view)
+    int m1_phase = -1;                 // last phase of ppqc_mode1_dist_phase run since ppqc_finalize_extremes (2: hours done)
     ppqc_timing timing{};
 };
 
@@ -420,7 +422,7 @@ int ppqc_destroy(ppqc_ctx* c) {
     void* ptrs[] = {r.rec_cnt, r.rec_hi, r.rec_lo, r.len, r.gc, r.nn, r.qsum, r.mean_q, r.err_hi, r.err_lo, r.flags,
                     r.channel, r.mux, r.time, r.hour, r.lens32, c->head, c->tail, c->res_buf, c->sk32, c->sk32_tmp, c->counts, c->vals, c->vals_tmp, c->sk64,
                     c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev, c->dense.base, c->fq.counts, c->fq.prefix,
-                    c->fq.block_sums, c->fq.line_off, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo};
+                    c->fq.block_sums, c->fq.line_off, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo, c->m1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->maxlen_host) (void)hipHostFree(c->maxlen_host);
@@ -814,6 +816,7 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     hipStream_t s = c->stream;
     resolve_finalize_timings(c);   // its events are about to be recorded again
     c->sum_fetched = false;
+    c->m1_phase = -1;
     // The result buffer is cleared on the auxiliary stream: this call is usually enqueued while the per-read kernels of
     // the batch still run, and nothing before the extremes kernel touches the results, so the clear costs no time on
     // the main stream.  If an earlier finalize phase may still be running (no synchronisation since), it stays in line.
@@ -881,7 +884,9 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const uint64_t n = c->n_reads;
-    if (c->cfg.time_mode == 1 && n) {
+    if (c->cfg.time_mode == 1 && c->m1_phase >= 0 && c->m1_phase != 2)
+        return fail(PPQC_E_STATE, "ppqc_mode1_dist_phase: phases 0, 1, 2 must all run before ppqc_finalize_tables");
+    if (c->cfg.time_mode == 1 && n && c->m1_phase != 2) {
         int64_t tmm[2];
         HIPCHK(hipMemcpyAsync(tmm, c->tminmax, 16, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -989,6 +994,13 @@ static int fetch_tables_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
     }
     const uint64_t* h = c->res_host;
     CHK(input_errors(h + c->res_words));
+    if (c->cfg.time_mode == 1 && c->m1_phase == 2) {
+        uint64_t oob = 0;
+        HIPCHK(hipMemcpy(&oob, c->m1 + 2 * (uint64_t)c->cfg.n_channels, 8, hipMemcpyDeviceToHost));
+        if (oob)
+            return fail(PPQC_E_RANGE, "time_mode 1 across ranks: " + std::to_string(oob) + " reads start outside the " +
+                                          std::to_string(PPQC_MODE1_DAYS) + "-day window around the reference time");
+    }
     const uint64_t nch = l.n_channels, nb = l.n_time_bins, cells = nch * l.n_mux * nb;
     uint64_t* hv = c->res_host;
 #define OUT(dst, off, cnt) do { if (view) dst = hv + (off); else if (dst) memcpy(dst, h + (off), (cnt) * 8); } while (0)
@@ -1107,6 +1119,37 @@ int ppqc_n50_select_early(ppqc_ctx* c, int round, int phase, void* stream) {
                                   round == 0, c->n50_out, ss));
         if (round == 2) c->n50_early = true;
     }
+    return mark_busy(c);
+}
+
+static int mode1_alloc(ppqc_ctx* c) {
+    if (c->m1) return PPQC_OK;
+    HIPCHK(hipMalloc((void**)&c->m1, mode1_dist_words(c->cfg.n_channels) * 8));
+    return PPQC_OK;
+}
+
+int ppqc_mode1_dist_view(ppqc_ctx* c, ppqc_mode1_tables* o) {
+    if (!c || !o) return fail(PPQC_E_INVALID, "null argument");
+    if (c->cfg.time_mode != 1) return fail(PPQC_E_STATE, "ppqc_mode1_dist_*: the context is not in time_mode 1");
+    HIPCHK(hipSetDevice(c->device));
+    CHK(mode1_alloc(c));
+    const uint64_t nch = c->cfg.n_channels;
+    o->first = c->m1; o->n_first = nch;
+    o->ties = c->m1 + nch; o->n_ties = nch + 1;
+    o->days = c->m1 + 2 * nch + 1; o->n_days = 2 * nch * PPQC_MODE1_DAYS;
+    return PPQC_OK;
+}
+
+int ppqc_mode1_dist_phase(ppqc_ctx* c, int phase) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    if (c->cfg.time_mode != 1) return fail(PPQC_E_STATE, "ppqc_mode1_dist_*: the context is not in time_mode 1");
+    if (phase < 0 || phase > 2) return fail(PPQC_E_INVALID, "phase must be 0, 1 or 2");
+    if (c->state < 1) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes first");
+    if (phase != c->m1_phase + 1) return fail(PPQC_E_STATE, "ppqc_mode1_dist_phase: phases run in the order 0, 1, 2");
+    HIPCHK(hipSetDevice(c->device));
+    CHK(mode1_alloc(c));
+    HIPCHK(launch_mode1_dist(phase, c->ra, c->n_reads, c->tp, c->m1, c->stream));
+    c->m1_phase = phase;
     return mark_busy(c);
 }
 

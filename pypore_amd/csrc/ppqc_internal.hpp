@@ -116,6 +116,10 @@ hipError_t launch_mode1_hours(ReadArrays ra, uint64_t n, const TableParams& tp, 
                               const uint32_t* sorted_vals, uint32_t* chan_start, uint32_t* first_desc,
                               hipStream_t s);
 
+// time_mode 1 across ranks (ppqc_tables.hip): phases 0, 1, 2 over buf = mode1_dist_words(n_channels) u64
+uint64_t mode1_dist_words(uint32_t n_channels);
+hipError_t launch_mode1_dist(int phase, ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* buf, hipStream_t s);
+
 // Hand-written LSD radix sort.  `counts` has 256*(n_waves+1)+256 u32; byte_mask selects which key bytes are sorted on.
 // sort_u32: the first pass reads `in`, later passes ping-pong between buf_a and buf_b (`in` may be buf_b: in place);
 // *out = the buffer that holds the sorted keys.  sort_u64_pairs sorts keys/vals in place (tmp_* are the ping-pong).

@@ -488,4 +488,116 @@ hipError_t launch_mode1_hours(ReadArrays ra, uint64_t n, const TableParams& tp, 
     return hipGetLastError();
 }
 
+
+// ---- time_mode 1 across ranks ----------------------------------------------------------------------------------------
+// The sort above needs all reads of a channel in one place.  The rule itself does not: with the reads of a channel in
+// start-time order, S = all of them but the first, a read is bumped iff it lies at or behind the first element of S whose
+// hour of day is below the hour of some EARLIER element of S (a sequence has a descent between neighbours iff it has an
+// element below its prefix maximum).  The hour of day rises with the time inside one day, so such an element can only be
+// undercut by elements of earlier days, and within a day the earliest element is the first to be: with, per channel and
+// day d, tmin[d] / tmax[d] = the earliest / latest start time of S in that day,
+//     T* = tmin[D] of the first day D with  hour(tmin[D]) < max over d < D of hour(tmax[d]),   bumped(read) = t >= T*.
+// (Reads tied in time have one hour: ties change nothing.)  So the ranks need to agree on three small tables only:
+//   phase 0: first[ch] = the earliest start of the channel                      (stored complemented -> all-reduce MAX)
+//   phase 1: ties[ch]  = reads starting at first[ch] (one of them is not in S)   (all-reduce SUM; ties[n_channels] counts
+//            days[ch][d] = tmax, ~tmin over the reads behind first[ch]           reads outside the day window)  (MAX)
+//   phase 2: T* per channel, then every read's hour from its own time.
+// Days are counted from the reference time, day -1 .. kMode1Days - 2 (day -1: a negative zone offset in front of it).
+constexpr int kMode1Days = PPQC_MODE1_DAYS;
+
+__device__ __forceinline__ int64_t mode1_day(int64_t t, const TableParams& tp) {
+    return floordiv64(t - tp.ref_time_s + tp.tz_offset_s, 24 * (int64_t)tp.bin_seconds) + 1;
+}
+
+__global__ __launch_bounds__(256) void mode1d_first_kernel(ReadArrays ra, uint64_t n, uint32_t nch, int64_t* first) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t ch = ra.channel[i];
+        const int64_t t = ra.time[i];
+        if (ch < 1 || ch > nch || t == INT64_MIN) continue;
+        if (~t > __hip_atomic_load(&first[ch - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax((long long*)&first[ch - 1], (long long)~t);
+    }
+}
+
+__global__ __launch_bounds__(256) void mode1d_days_kernel(ReadArrays ra, uint64_t n, TableParams tp,
+                                                          const int64_t* __restrict__ first, uint64_t* ties,
+                                                          int64_t* dmax, int64_t* dmin) {
+    const uint32_t nch = tp.lay.n_channels;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t ch = ra.channel[i];
+        const int64_t t = ra.time[i];
+        if (ch < 1 || ch > nch || t == INT64_MIN) continue;
+        if (t == ~first[ch - 1]) { atomicAdd((unsigned long long*)&ties[ch - 1], 1ull); continue; }
+        const int64_t d = mode1_day(t, tp);
+        if (d < 0 || d >= kMode1Days) { atomicAdd((unsigned long long*)&ties[nch], 1ull); continue; }
+        const uint64_t k = (uint64_t)(ch - 1) * kMode1Days + (uint64_t)d;
+        if (t > __hip_atomic_load(&dmax[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((long long*)&dmax[k], (long long)t);
+        if (~t > __hip_atomic_load(&dmin[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((long long*)&dmin[k], (long long)~t);
+    }
+}
+
+// one thread per channel: first[ch] <- T* (INT64_MAX: no read of the channel is bumped)
+__global__ __launch_bounds__(256) void mode1d_pick_kernel(TableParams tp, int64_t* first, const uint64_t* __restrict__ ties,
+                                                          const int64_t* __restrict__ dmax, const int64_t* __restrict__ dmin) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= tp.lay.n_channels) return;
+    const int64_t f = first[c];
+    int64_t tstar = INT64_MAX;
+    if (f != INT64_MIN) {   // the channel has a timed read
+        const int64_t t0 = ~f;
+        const bool t0_in_s = ties[c] >= 2;
+        const int64_t d0 = mode1_day(t0, tp);   // may lie outside the window: then it matches no d below (and the run fails)
+        int32_t m = -1;
+        for (int d = 0; d < kMode1Days; ++d) {
+            int64_t mx = dmax[(uint64_t)c * kMode1Days + d], mn = ~dmin[(uint64_t)c * kMode1Days + d];
+            bool any = mx != INT64_MIN;
+            if (t0_in_s && d == d0) { mn = t0; if (!any) mx = t0; any = true; }
+            if (!any) continue;
+            if (hour_of_day(mn, tp) < m) { tstar = mn; break; }
+            const int32_t h = hour_of_day(mx, tp);
+            m = h > m ? h : m;
+        }
+    }
+    first[c] = tstar;
+}
+
+__global__ __launch_bounds__(256) void mode1d_assign_kernel(ReadArrays ra, uint64_t n, TableParams tp,
+                                                            const int64_t* __restrict__ tstar) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ch = ra.channel[i];
+    const int64_t t = ra.time[i];
+    int32_t hour = -1;
+    if (ch >= 1 && ch <= tp.lay.n_channels && t != INT64_MIN) {
+        const int32_t h = hour_of_day(t, tp) + (t >= tstar[ch - 1] ? 24 : 0);
+        hour = h < (int32_t)tp.lay.n_time_bins ? h : -1;
+    }
+    ra.hour[i] = hour;
+}
+
+uint64_t mode1_dist_words(uint32_t n_channels) { return 2ull * n_channels + 1 + 2ull * n_channels * kMode1Days; }
+
+// buf = [first: nch | ties: nch + 1 | dmax: nch * D | dmin: nch * D]
+hipError_t launch_mode1_dist(int phase, ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* buf, hipStream_t s) {
+    const uint32_t nch = tp.lay.n_channels;
+    int64_t* first = (int64_t*)buf;
+    uint64_t* ties = buf + nch;
+    int64_t* dmax = (int64_t*)(ties + nch + 1);
+    int64_t* dmin = dmax + (uint64_t)nch * kMode1Days;
+    const unsigned grid = grid_for(n ? n : 1, 2048);
+    if (phase == 0) {
+        hipError_t e = launch_fill_u64(buf, nch, (uint64_t)INT64_MIN, s);                        // ~INT64_MAX: unseen
+        if (e == hipSuccess) e = hipMemsetAsync(ties, 0, (nch + 1) * 8, s);
+        if (e == hipSuccess) e = launch_fill_u64((uint64_t*)dmax, 2ull * nch * kMode1Days, (uint64_t)INT64_MIN, s);
+        if (e != hipSuccess) return e;
+        if (n) hipLaunchKernelGGL(mode1d_first_kernel, dim3(grid), dim3(256), 0, s, ra, n, nch, first);
+    } else if (phase == 1) {
+        if (n) hipLaunchKernelGGL(mode1d_days_kernel, dim3(grid), dim3(256), 0, s, ra, n, tp, first, ties, dmax, dmin);
+    } else {
+        hipLaunchKernelGGL(mode1d_pick_kernel, dim3((nch + 255) / 256), dim3(256), 0, s, tp, first, ties, dmax, dmin);
+        if (n) hipLaunchKernelGGL(mode1d_assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ra, n, tp, first);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace ppqc

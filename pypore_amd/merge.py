@@ -18,7 +18,11 @@ FastStats (lib/seq_routines.py:103-108):
   (early=False, or a context that cannot tell its index-only results early: the same merges as four collectives behind
   the kernel, the first select histogram fused into the table buffer's all-reduce)
 
-time_mode 1 (the reference's per-channel hour-wrap quirk) needs all reads of a channel on one rank: shard by channel.
+time_mode 1 (the reference's per-channel hour-wrap quirk, lib/fast5_reader.py:117-126) is defined on a channel's reads
+in start-time order, but it needs no reads in one place: the ranks agree on three small per-channel tables instead (the
+channel's earliest start, the reads tied at it, per day the earliest and latest start of the others; three more small
+all-reduces, ppqc_mode1_dist_phase) and every rank then bins its own reads.  So the CLI shards FILES, whatever channels
+they hold (``shard_files``).  ``mode1_hours_reference`` is the same arithmetic on host arrays, for the tests.
 """
 from __future__ import annotations
 
@@ -33,6 +37,8 @@ def allreduce_table_tensors(sum_t, max_t, min_t, dist, group=None):
 def gather_lengths(lengths_t, dist, torch, group=None):
     """All-gather of per-rank length vectors of different sizes (zero padding does not change N50)."""
     world = dist.get_world_size(group)
+    if lengths_t.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.current_stream().synchronize()      # see _all_reduce
     n = torch.tensor([lengths_t.numel()], dtype=torch.int64, device=lengths_t.device)
     dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
     nmax = int(n.item())
@@ -41,6 +47,16 @@ def gather_lengths(lengths_t, dist, torch, group=None):
     out = torch.empty(nmax * world, dtype=lengths_t.dtype, device=lengths_t.device)
     dist.all_gather_into_tensor(out, padded, group=group)
     return out
+
+
+def _all_reduce(dist, torch, t, op, group=None):
+    """dist.all_reduce of a device tensor.  RCCL ("nccl") is stream-ordered: nothing waits.  gloo (the two-ranks-on-one-GPU
+    rehearsal and the CPU tests) stages a device tensor through the host from a worker thread; handed a tensor whose
+    producer kernels are still queued on the stream it hung about one run in three on this pool, and never when the
+    stream was idle: the stream is drained first, which costs that backend nothing it was not going to pay."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.current_stream().synchronize()
+    dist.all_reduce(t, op=op, group=group)
 
 
 _SIDE = {}
@@ -73,6 +89,8 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, 
     handle = torch.cuda.current_stream().cuda_stream
     if ctx.external_stream != handle:
         ctx.set_stream(handle)
+    if ctx.cfg.time_mode == 1:
+        return _finalize_mode1(ctx, dist, torch, group, copy)
     if early is None:
         early = n50 == "select" and ctx.index_early()
     if early:
@@ -81,37 +99,37 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, 
         views, _ = ctx.device_tables()
         with torch.cuda.stream(side):
             t_maxmin = torch.as_tensor(views["maxmin"], device="cuda")
-            dist.all_reduce(t_maxmin, op=dist.ReduceOp.MAX, group=group)
+            _all_reduce(dist, torch, t_maxmin, dist.ReduceOp.MAX, group)
             t_sel = torch.as_tensor(views["sel"], device="cuda")
             for r in range(3):
                 ctx.n50_select_early(r, 0, side.cuda_stream)
-                dist.all_reduce(t_sel, op=dist.ReduceOp.SUM, group=group)
+                _all_reduce(dist, torch, t_sel, dist.ReduceOp.SUM, group)
                 ctx.n50_select_early(r, 1, side.cuda_stream)
         torch.cuda.current_stream().wait_stream(side)
         ctx.finalize_extremes()
         ctx.finalize_tables()                    # uses the merged max_len; the N50 is final already
         t_sum = torch.as_tensor(views["sum"], device="cuda")
-        dist.all_reduce(t_sum, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(dist, torch, t_sum, dist.ReduceOp.SUM, group)
         return ctx.fetch_tables(copy=copy)
     ctx.finalize_extremes()
     views, _ = ctx.device_tables()
     # the device keeps the minima complemented, so maxima and minima merge in ONE all-reduce(MAX)
     t_maxmin = torch.as_tensor(views["maxmin"], device="cuda")
-    dist.all_reduce(t_maxmin, op=dist.ReduceOp.MAX, group=group)
+    _all_reduce(dist, torch, t_maxmin, dist.ReduceOp.MAX, group)
     ctx.finalize_tables()                        # length histogram bins use the merged max_len
     if n50 == "select":
         t_sum_sel = torch.as_tensor(views["sum_sel"], device="cuda")
         t_sel = torch.as_tensor(views["sel"], device="cuda")
         ctx.n50_select_hist(0)
-        dist.all_reduce(t_sum_sel, op=dist.ReduceOp.SUM, group=group)      # tables + first select histogram
+        _all_reduce(dist, torch, t_sum_sel, dist.ReduceOp.SUM, group)      # tables + first select histogram
         ctx.n50_select_pick(0)
         for r in (1, 2):
             ctx.n50_select_hist(r)
-            dist.all_reduce(t_sel, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce(dist, torch, t_sel, dist.ReduceOp.SUM, group)
             ctx.n50_select_pick(r)
         return ctx.fetch_tables(copy=copy)
     t_sum = torch.as_tensor(views["sum"], device="cuda")
-    dist.all_reduce(t_sum, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce(dist, torch, t_sum, dist.ReduceOp.SUM, group)
     n_local = views["lengths"].__cuda_array_interface__["shape"][0]
     if n_local:
         lens = torch.as_tensor(views["lengths"], device="cuda")
@@ -121,6 +139,108 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, 
     ctx.finalize_n50(all_lens.data_ptr(), all_lens.numel())
     tables = ctx.fetch_tables(copy=copy)         # synchronises: all_lens may be released afterwards
     return tables
+
+
+def _finalize_mode1(ctx, dist, torch, group, copy):
+    """time_mode 1: extremes -> MAX; the three phases of the hour rule with their merges; tables (+ first select
+    histogram) -> SUM; two more select rounds.  Seven small collectives and one table-sized one, all stream-ordered."""
+    ctx.finalize_extremes()
+    views, _ = ctx.device_tables()
+    t_maxmin = torch.as_tensor(views["maxmin"], device="cuda")
+    _all_reduce(dist, torch, t_maxmin, dist.ReduceOp.MAX, group)
+    m1 = ctx.mode1_dist_tables()
+    ctx.mode1_dist_phase(0)
+    _all_reduce(dist, torch, torch.as_tensor(m1["first"], device="cuda"), dist.ReduceOp.MAX, group)
+    ctx.mode1_dist_phase(1)
+    _all_reduce(dist, torch, torch.as_tensor(m1["ties"], device="cuda"), dist.ReduceOp.SUM, group)
+    _all_reduce(dist, torch, torch.as_tensor(m1["days"], device="cuda"), dist.ReduceOp.MAX, group)
+    ctx.mode1_dist_phase(2)
+    ctx.finalize_tables()
+    t_sum_sel = torch.as_tensor(views["sum_sel"], device="cuda")
+    t_sel = torch.as_tensor(views["sel"], device="cuda")
+    ctx.n50_select_hist(0)
+    _all_reduce(dist, torch, t_sum_sel, dist.ReduceOp.SUM, group)
+    ctx.n50_select_pick(0)
+    for r in (1, 2):
+        ctx.n50_select_hist(r)
+        _all_reduce(dist, torch, t_sel, dist.ReduceOp.SUM, group)
+        ctx.n50_select_pick(r)
+    return ctx.fetch_tables(copy=copy)
+
+
+def allreduce_min_int(value, dist, torch, group=None, device="cuda"):
+    """MIN over the ranks of one host integer (RefTime of a FASTQ-only run: the earliest start time of the job)."""
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item())
+
+
+def shard_files(files, rank, world):
+    """Contiguous shard of a file list: rank r takes files [r F / N, (r + 1) F / N).  Contiguous, so that the reads of a
+    channel keep their order (file order, then record order) when the ranks' outputs are put together in rank order
+    (-fq).  The counterpart of the reference handing one task per channel / per file to its pool of worker processes
+    (lib/seq_routines.py:909-923, 975-990)."""
+    files = list(files)
+    return files[rank * len(files) // world:(rank + 1) * len(files) // world]
+
+
+MODE1_DAYS = 64   # PPQC_MODE1_DAYS
+
+
+def mode1_hours_reference(channel, time, cfg, all_reduce_max, all_reduce_sum):
+    """The arithmetic of ppqc_mode1_dist_phase 0 / 1 / 2 on host arrays (tests): ``channel`` / ``time`` are this rank's
+    reads, ``all_reduce_max`` / ``all_reduce_sum`` merge an int64 numpy array across the ranks in place.  Returns this
+    rank's hour bins (-1 = none) and the merged count of reads outside the day window."""
+    import numpy as np
+    nch, nb = int(cfg["n_channels"]), int(cfg["n_time_bins"])
+    bs, ref, tz = int(cfg["bin_seconds"]), int(cfg["ref_time_s"]), int(cfg["tz_offset_s"])
+    ch = np.asarray(channel, dtype=np.int64)
+    t = np.asarray(time, dtype=np.int64)
+    NONE = np.iinfo(np.int64).min
+    ok = (ch >= 1) & (ch <= nch) & (t != NONE)
+    hod = lambda x: ((x - ref + tz) // bs) % 24
+    day = lambda x: (x - ref + tz) // (24 * bs) + 1
+    first = np.full(nch, NONE, np.int64)                       # ~t0, unseen = ~INT64_MAX
+    np.maximum.at(first, ch[ok] - 1, ~t[ok])
+    all_reduce_max(first)
+    ties = np.zeros(nch + 1, np.int64)
+    days = np.full(2 * nch * MODE1_DAYS, NONE, np.int64)
+    dmax, dmin = days[:nch * MODE1_DAYS], days[nch * MODE1_DAYS:]
+    tie = ok.copy()
+    tie[ok] = t[ok] == ~first[ch[ok] - 1]
+    np.add.at(ties, ch[tie] - 1, 1)
+    rest = ok & ~tie
+    d = day(t[rest])
+    inside = (d >= 0) & (d < MODE1_DAYS)
+    ties[nch] += int((~inside).sum())
+    k = (ch[rest][inside] - 1) * MODE1_DAYS + d[inside]
+    np.maximum.at(dmax, k, t[rest][inside])
+    np.maximum.at(dmin, k, ~t[rest][inside])
+    all_reduce_sum(ties)
+    all_reduce_max(days)
+    tstar = np.full(nch, np.iinfo(np.int64).max, np.int64)
+    for c in range(nch):
+        if first[c] == NONE:
+            continue
+        t0 = int(~first[c])
+        d0, m = int(day(t0)), -1
+        for dd in range(MODE1_DAYS):
+            mx, mn = int(dmax[c * MODE1_DAYS + dd]), int(~dmin[c * MODE1_DAYS + dd])
+            any_ = mx != NONE
+            if ties[c] >= 2 and dd == d0:
+                mn = t0
+                mx = mx if any_ else t0
+                any_ = True
+            if not any_:
+                continue
+            if hod(mn) < m:
+                tstar[c] = mn
+                break
+            m = max(m, int(hod(mx)))
+    hours = np.full(len(t), -1, np.int32)
+    h = hod(t[ok]) + np.where(t[ok] >= tstar[ch[ok] - 1], 24, 0)
+    hours[ok] = np.where(h < nb, h, -1)
+    return hours, int(ties[nch])
 
 
 SELECT_ROUNDS = ((21, 11), (10, 11), (0, 10))    # (shift, bits) of ppqc_n50_select_hist / _pick

@@ -304,6 +304,17 @@ class QCContext:
                      sum_sel=DeviceArrayView(d.sum_buf, d.n_sum + d.n_sel, "<i8", self))
         return views, d
 
+    def mode1_dist_tables(self):
+        """time_mode 1 across ranks: zero-copy device views {first (MAX), ties (SUM), days (MAX)} (int64) that the caller
+        all-reduces between the phases of ``mode1_dist_phase`` (include/pypore_qc.h, ppqc_mode1_dist_phase)."""
+        m = L.Mode1Tables()
+        L.check(self._lib.ppqc_mode1_dist_view(self._ctx, C.byref(m)))
+        return dict(first=DeviceArrayView(m.first, m.n_first, "<i8", self), ties=DeviceArrayView(m.ties, m.n_ties, "<i8", self),
+                    days=DeviceArrayView(m.days, m.n_days, "<i8", self))
+
+    def mode1_dist_phase(self, phase):
+        L.check(self._lib.ppqc_mode1_dist_phase(self._ctx, int(phase)))
+
     def timings(self):
         t = L.Timing()
         L.check(self._lib.ppqc_timings(self._ctx, C.byref(t)))
