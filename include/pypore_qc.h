@@ -230,6 +230,12 @@ int ppqc_submit_records(ppqc_ctx* ctx, const ppqc_records* host_records);
 int ppqc_submit_fastq(ppqc_ctx* ctx, const uint8_t* host_text, uint64_t n, int slot, uint8_t mux, uint64_t* n_records);
 int ppqc_submit_fastq_device(ppqc_ctx* ctx, const uint8_t* device_text, uint64_t n, uint8_t mux, uint64_t* n_records);
 int ppqc_sync(ppqc_ctx* ctx);
+/* Blocks until the H2D copies of the newest ppqc_submit / ppqc_submit_fastq on staging slot 0|1 have completed, i.e. until
+ * that call's host batch may be overwritten -- without waiting for the kernels behind them as ppqc_sync does.  It is
+ * what lets a loader thread refill a pinned host buffer while the other slot's batch is in flight (the reference's
+ * counterpart is the worker pool pulling the next task while results are still being merged, lib/seq_routines.py:916-942).
+ * Returns at once if the slot has not been used. */
+int ppqc_slot_wait(ppqc_ctx* ctx, int slot);
 /* Input problems found on the device since create / reset: out[0] malformed rows of device CSR batches, out[1]
  * malformed FASTQ records, out[2] number of the first of those within its text (UINT64_MAX if none), out[3] quality
  * bytes outside '!'..'~' seen by the GPU tokenizer (reported like n_bad_qual of ppqc_fastq_pack; [0] and [1] also make

@@ -31,7 +31,7 @@ SYMBOLS = (
     "ppqc_finalize_tables", "ppqc_finalize_n50", "ppqc_fetch_tables", "ppqc_fetch_tables_view", "ppqc_finalize", "ppqc_finalize_view", "ppqc_device_tables_view",
     "ppqc_timings", "ppqc_reset_timings", "ppqc_sort_u32_device", "ppqc_sort_u32_device_static", "ppqc_synth_fill_device", "ppqc_fastq_scan", "ppqc_fastq_pack",
     "ppqc_submit_fastq", "ppqc_submit_fastq_device", "ppqc_input_errors", "ppqc_time_range", "ppqc_set_ref_time", "ppqc_n50_select_hist", "ppqc_n50_select_pick", "ppqc_index_early", "ppqc_stream_wait_index", "ppqc_n50_select_early", "ppqc_set_stream",
-    "ppqc_mode1_dist_view", "ppqc_mode1_dist_phase",
+    "ppqc_mode1_dist_view", "ppqc_mode1_dist_phase", "ppqc_slot_wait",
 )
 
 
@@ -132,7 +132,7 @@ def load():
         "ppqc_alloc_pinned": [C.POINTER(P), C.c_size_t], "ppqc_free_pinned": [P],
         "ppqc_submit": [P, C.POINTER(Batch), C.c_int], "ppqc_submit_device": [P, C.POINTER(Batch)],
         "ppqc_submit_records": [P, C.POINTER(Records)],
-        "ppqc_sync": [P], "ppqc_n_reads": [P, C.POINTER(C.c_uint64)],
+        "ppqc_sync": [P], "ppqc_slot_wait": [P, C.c_int], "ppqc_n_reads": [P, C.POINTER(C.c_uint64)],
         "ppqc_read_stats": [P, C.POINTER(PerRead), C.c_uint64, C.c_uint64],
         "ppqc_read_hours": [P, P, C.c_uint64, C.c_uint64],
         "ppqc_finalize_extremes": [P], "ppqc_finalize_tables": [P],

@@ -54,6 +54,7 @@ struct Slot {   // device staging for one host batch
     uint64_t cap_bytes = 0, cap_reads = 0;
     hipEvent_t copied = nullptr, done = nullptr;
     bool busy = false;
+    bool used = false;   // `copied` has been recorded at least once
 };
 
 struct EvPair {
@@ -593,6 +594,7 @@ int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
     HIPCHK(hipMemcpyAsync(s.time, b->start_time_s, R * 8, hipMemcpyHostToDevice, cs));
     if (b->fail_flag) HIPCHK(hipMemcpyAsync(s.ff, b->fail_flag, R, hipMemcpyHostToDevice, cs));
     HIPCHK(hipEventRecord(s.copied, cs));
+    s.used = true;
     HIPCHK(hipStreamWaitEvent(c->stream, s.copied, 0));
     ppqc_batch d = *b;
     d.bases = s.bases; d.quals = s.quals; d.offsets = s.offsets; d.channel = s.channel; d.mux = s.mux;
@@ -674,6 +676,7 @@ int ppqc_submit_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, int si, uint
     hipStream_t cs = c->copy[si];
     HIPCHK(hipMemcpyAsync(s.bases, text, n, hipMemcpyHostToDevice, cs));
     HIPCHK(hipEventRecord(s.copied, cs));
+    s.used = true;
     HIPCHK(hipStreamWaitEvent(c->stream, s.copied, 0));
     CHK(run_fastq(c, s.bases, n, mux, n_records));
     HIPCHK(hipEventRecord(s.done, c->stream));
@@ -767,6 +770,14 @@ int ppqc_sync(ppqc_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 2; ++i) c->slot[i].busy = false;
     c->res_busy = false;
+    return PPQC_OK;
+}
+
+int ppqc_slot_wait(ppqc_ctx* c, int si) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    if (si < 0 || si > 1) return fail(PPQC_E_INVALID, "slot must be 0 or 1");
+    if (!c->slot[si].used) return PPQC_OK;
+    HIPCHK(hipEventSynchronize(c->slot[si].copied));
     return PPQC_OK;
 }
 

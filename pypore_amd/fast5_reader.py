@@ -79,13 +79,15 @@ def Pathcheck(f5, fail):
     return [p for p in paths if p in visits]
 
 
-def get_content(f, h5_open=None):
+def get_content(f, h5_open=None, p_check=None):
     """One read (lib/fast5_reader.py:36-71): (mux, start_time, fail, title, bases, quals).  A path containing 'fail'
-    yields no sequence (the reference keeps ReadLength 0, QScore 6.99, GC 0 for it, :37-40, 52)."""
+    yields no sequence (the reference keeps ReadLength 0, QScore 6.99, GC 0 for it, :37-40, 52).  ``p_check``: the group
+    names found by ONE visit of a file of the channel, as the reference passes them in (:96-105); a fail path uses its
+    first three entries only."""
     fail = 'fail' in f
     read_number = int(re.sub(r'.*read', 'read', f).split('_')[1])
     with (h5_open or default_h5_open)(f, 'r') as f5:
-        dp = Pathcheck(f5, fail)
+        dp = p_check if p_check is not None else Pathcheck(f5, fail)
         mux = int(f5['%s/Read_%d' % (dp[0], read_number)].attrs['start_mux'])
         _channel = _text(f5[dp[1]].attrs['channel_number'])      # read like the reference does; unused there too (:106)
         stamp = _text(f5['Analyses/Segmentation_000'].attrs['time_stamp'])
@@ -98,27 +100,43 @@ def get_content(f, h5_open=None):
     return mux, int(mktime_local(stamp)), fail, title, bases, quals
 
 
-def _pack(recs):
-    n = len(recs)
-    off = np.zeros(n + 1, np.uint64)
-    if n:
-        off[1:] = np.cumsum([len(r[5]) for r in recs])
-    return dict(n_reads=n, bases=np.frombuffer(b"".join(r[5] for r in recs), np.uint8),
-                quals=np.frombuffer(b"".join(r[6] for r in recs), np.uint8), offsets=off,
-                channel=np.asarray([r[0] for r in recs], np.uint32), mux=np.asarray([r[1] for r in recs], np.uint8),
-                start_time=np.asarray([r[2] for r in recs], np.int64),
-                fail_flag=np.asarray([r[3] for r in recs], np.uint8), titles=[r[4] for r in recs])
+def channel_path_checks(files, h5_open=None):
+    """The reference visits ONE file per channel -- the first whose path contains 'pass', else the first with 'fail',
+    else the channel's first file -- and hands the group names found there to every get_content of the channel
+    (lib/fast5_reader.py:95-105).  Returns {channel: names}; a channel whose probe file cannot be read gets None (its
+    reads then fail one by one, as they would in the reference's ``except: del ds``)."""
+    first = {}
+    for f in files:
+        ch = channel_of(f)
+        cur = first.get(ch)
+        rank = 0 if 'pass' in f else (1 if 'fail' in f else 2)
+        if cur is None or rank < cur[0]:
+            first[ch] = (rank, f)
+    out = {}
+    for ch, (_r, f) in first.items():
+        try:
+            with (h5_open or default_h5_open)(f, 'r') as f5:
+                out[ch] = Pathcheck(f5, 'fail' in f)
+        except (KeyError, IndexError, ValueError, OSError) as e:
+            log.debug("path check of %s failed: %s" % (f, e))
+            out[ch] = None
+    return out
 
 
-def load_batches(files, n_channels=512, threads=1, h5_open=None, batch_reads=4000):
-    """CSR batches of ``batch_reads`` reads.  Unreadable reads are skipped as in the reference's
-    ``except: del ds`` (lib/fast5_reader.py:104-116); a file name without a channel field raises like :910."""
+def iter_record_batches(files, n_channels=512, threads=1, h5_open=None, batch_reads=4000):
+    """Lists of loader records ``(channel, mux, start_time, fail, title, bases, quals)``, ``batch_reads`` files at a
+    time.  Unreadable reads are skipped as in the reference's ``except: del ds`` (lib/fast5_reader.py:104-116); a file
+    name without a channel field raises like :910."""
+    checks = channel_path_checks(files, h5_open)
+
     def one(f):
         ch = channel_of(f)
         if ch < 1 or ch > n_channels:
             raise IndexError("channel %d of %s outside 1..%d" % (ch, f, n_channels))
         try:
-            mux, t, fail, title, b, q = get_content(f, h5_open)
+            if checks.get(ch) is None:
+                raise KeyError("no usable path check for channel %d" % ch)
+            mux, t, fail, title, b, q = get_content(f, h5_open, checks[ch])
         except (KeyError, IndexError, ValueError, OSError) as e:
             log.debug("skipping %s: %s" % (f, e))
             return None
@@ -126,5 +144,11 @@ def load_batches(files, n_channels=512, threads=1, h5_open=None, batch_reads=400
 
     with ThreadPoolExecutor(max_workers=max(1, int(threads))) as pool:
         for a in range(0, len(files), batch_reads):
-            recs = [r for r in pool.map(one, files[a:a + batch_reads]) if r is not None]
-            yield _pack(recs)
+            yield [r for r in pool.map(one, files[a:a + batch_reads]) if r is not None]
+
+
+def load_batches(files, n_channels=512, threads=1, h5_open=None, batch_reads=4000):
+    """The same as CSR batches in fresh (pageable) arrays; the CLI packs into pinned slots instead (staging.py)."""
+    from .staging import pack_records
+    for recs in iter_record_batches(files, n_channels, threads, h5_open, batch_reads):
+        yield pack_records(recs)

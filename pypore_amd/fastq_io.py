@@ -25,6 +25,35 @@ def read_text(path):
         return fh.read()
 
 
+def read_text_into(path, slot):
+    """The file's bytes read STRAIGHT into the pinned slot's text arena (``readinto``: no pageable copy of a plain
+    .fastq; a .gz is inflated into it).  Returns the uint8 view of the text."""
+    if str(path).endswith(".gz"):
+        with gzip.open(path, "rb") as fh:
+            n, cap = 0, max(slot.text_capacity(), 1 << 20)
+            buf = slot.text(cap)
+            while True:
+                got = fh.readinto(memoryview(buf)[n:])
+                if not got:
+                    break
+                n += got
+                if n == len(buf):           # full: grow (the arena is reallocated, so carry the bytes over)
+                    keep = buf[:n].copy()
+                    buf = slot.text(2 * len(buf))
+                    buf[:n] = keep
+            return buf[:n]
+    size = os.path.getsize(path)
+    buf = slot.text(size)
+    with open(path, "rb", buffering=0) as fh:
+        n = 0
+        while n < size:
+            got = fh.readinto(memoryview(buf)[n:])
+            if not got:
+                break
+            n += got
+    return buf[:n]
+
+
 def pack_fastq(text, final=True, first=True):
     """Tokenise FASTQ text (``first``: the block starts the file, where SeqIO rejects a blank line).  Returns a dict with the CSR arrays (``bases``, ``quals``, ``offsets``), per-record
     ``channel`` (0 if the header has no ch=), ``start_time`` (INT64_MIN if absent), header spans, ``n_bad_qual``

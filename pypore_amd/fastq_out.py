@@ -42,11 +42,17 @@ class BgzfWriter:
             self._block(self._buf[:_BLOCK])
             del self._buf[:_BLOCK]
 
-    def close(self):
+    def flush(self):
+        """End the current block here (a block boundary is a point where BGZF streams can be cut and joined)."""
         if self._buf:
             self._block(self._buf)
             self._buf = bytearray()
-        self._fh.write(_EOF)
+        return self._fh.tell()
+
+    def close(self, eof=True):
+        self.flush()
+        if eof:
+            self._fh.write(_EOF)
         self._fh.close()
 
     def __enter__(self):
@@ -56,15 +62,54 @@ class BgzfWriter:
         self.close()
 
 
-def _write(records, path):
-    """records: iterable of (title: bytes, bases: bytes, quals: bytes)."""
+def _write(records, path, channels=None):
+    """records: iterable of (title: bytes, bases: bytes, quals: bytes).  ``channels`` (one per record, non-decreasing):
+    write a PART of a multi-GPU run instead -- a block ends with every channel, no end-of-file block, and
+    ``path + '.idx'`` lists (channel, first byte, end byte) so that stitch_parts can cut the part at channel boundaries."""
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
     n = 0
-    with BgzfWriter(path) as out:
-        for title, s, q in records:
+    out = BgzfWriter(path)
+    index, cur, start = [], None, 0
+    try:
+        for k, (title, s, q) in enumerate(records):
+            if channels is not None and channels[k] != cur:
+                pos = out.flush()
+                if cur is not None:
+                    index.append((int(cur), start, pos))
+                cur, start = channels[k], pos
             out.write(b"@" + title + b"\n" + s + b"\n+\n" + q + b"\n")
             n += 1
+        if channels is not None:
+            pos = out.flush()
+            if cur is not None:
+                index.append((int(cur), start, pos))
+    finally:
+        out.close(eof=channels is None)
+    if channels is not None:
+        import json
+        with open(path + ".idx", "w") as fh:
+            json.dump(index, fh)
     return n
+
+
+def stitch_parts(parts, path, n_channels):
+    """The ranks' parts put together: channel by channel, ranks in order (each rank holds a contiguous share of the job's
+    files, so this is the order one process would have written), then the end-of-file block.  The parts are removed."""
+    import json
+    idx = [{c: (a, e) for c, a, e in json.load(open(p + ".idx"))} for p in parts]
+    fhs = [open(p, "rb") for p in parts]
+    with open(path, "wb") as out:
+        for c in sorted(set().union(*[set(i) for i in idx])):
+            for i, fh in zip(idx, fhs):
+                if c in i:
+                    a, e = i[c]
+                    fh.seek(a)
+                    out.write(fh.read(e - a))
+        out.write(_EOF)
+    for fh, p in zip(fhs, parts):
+        fh.close()
+        os.remove(p)
+        os.remove(p + ".idx")
 
 
 def passing_order(channel, flags):
@@ -73,7 +118,7 @@ def passing_order(channel, flags):
     return keep[np.argsort(np.asarray(channel)[keep], kind="stable")]
 
 
-def write_passing(packed, per_read, path):
+def write_passing(packed, per_read, path, n_channels=None, part=False):
     """``packed``: list of (file path, pack_fastq() result) in submission order; ``per_read``: read_stats() of the run."""
     titles, seqs, quals, chans = [], [], [], []
     for _p, p in packed:
@@ -87,10 +132,10 @@ def write_passing(packed, per_read, path):
         chans.append(p["channel"])
     chan = np.concatenate(chans) if chans else np.zeros(0, np.uint32)
     order = passing_order(chan, per_read["flags"][:len(chan)])
-    return _write(((titles[i], seqs[i], quals[i]) for i in order), path)
+    return _write(((titles[i], seqs[i], quals[i]) for i in order), path, chan[order] if part else None)
 
 
-def write_passing_batches(batches, per_read, path):
+def write_passing_batches(batches, per_read, path, n_channels=None, part=False):
     """Same for loader batches that kept their FASTQ titles (``titles`` list per batch)."""
     titles, seqs, quals, chans = [], [], [], []
     for b in batches:
@@ -103,4 +148,4 @@ def write_passing_batches(batches, per_read, path):
         chans.append(b["channel"])
     chan = np.concatenate(chans) if chans else np.zeros(0, np.uint32)
     order = passing_order(chan, per_read["flags"][:len(chan)])
-    return _write(((titles[i], seqs[i], quals[i]) for i in order), path)
+    return _write(((titles[i], seqs[i], quals[i]) for i in order), path, chan[order] if part else None)

@@ -6,7 +6,7 @@ from __future__ import annotations
 import os
 from concurrent.futures import ThreadPoolExecutor
 
-from .fast5_reader import default_h5_open, mktime_local, _text, _pack, FASTQ_PATH
+from .fast5_reader import default_h5_open, mktime_local, _text, FASTQ_PATH
 from .logging_module import log
 
 
@@ -49,11 +49,32 @@ def read_file(path, h5_open=None):
     return recs, ref_start
 
 
+def ref_start_of(files, h5_open=None):
+    """RefStart of a run: exp_start_time of the first read of the first file that has one.  The reference ends up with
+    the value of whichever file's result is scanned last (lib/seq_routines.py:989-994: every float in support_list
+    overwrites it); all files of a run share one exp_start_time."""
+    for f in files:
+        try:
+            with (h5_open or default_h5_open)(f, 'r') as f5:
+                reads = list(f5.keys())
+                if reads:
+                    return mktime_local(_text(f5[str(reads[0]) + '/tracking_id'].attrs['exp_start_time']))
+        except (KeyError, IndexError, ValueError, OSError) as e:
+            log.debug("no exp_start_time in %s: %s" % (f, e))
+    return None
+
+
+def iter_record_batches(files, threads=1, h5_open=None):
+    """One list of loader records per file, files read ``threads`` at a time, in file order."""
+    with ThreadPoolExecutor(max_workers=max(1, int(threads))) as pool:
+        for recs, _ref in pool.map(lambda f: read_file(f, h5_open), files):
+            yield recs
+
+
 def load_batches(files, threads=1, h5_open=None):
-    """(list of CSR batches, RefStart).  The reference ends up with the RefStart of whichever file's result is
-    scanned last (lib/seq_routines.py:989-994: every float in support_list overwrites it); all files of a run share
-    one exp_start_time, so the first file's value is used."""
+    """(list of CSR batches in fresh arrays, RefStart); the CLI packs into pinned slots instead (staging.py)."""
+    from .staging import pack_records
     with ThreadPoolExecutor(max_workers=max(1, int(threads))) as pool:
         out = list(pool.map(lambda f: read_file(f, h5_open), files))
     ref = next((r for _recs, r in out if r is not None), 0)
-    return [_pack(recs) for recs, _r in out], ref
+    return [pack_records(recs) for recs, _r in out], ref

@@ -28,6 +28,9 @@ class DeviceArrayView:
         self._owner = owner
 
 
+SUBMIT_HOOK = None   # tests: called with (kind, {name: (address, nbytes)}) for every host batch handed to the library
+
+
 class QCContext:
     def __init__(self, device=0, n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=0,
                  tz_offset_s=0, ref_time_s=0, fail_q=7.0, max_reads_hint=0, compat_flags=0):
@@ -83,6 +86,9 @@ class QCContext:
         if len(bases) < nbytes or len(quals) < nbytes:
             raise ValueError("bases/quals shorter than offsets[-1]")
         b = L.Batch(R, nbytes, _ptr(bases), _ptr(quals), _ptr(offsets), _ptr(channel), _ptr(mux), _ptr(t), _ptr(ff))
+        if SUBMIT_HOOK is not None:
+            SUBMIT_HOOK("csr", {k: (a.ctypes.data, a.nbytes) for k, a in (("bases", bases), ("quals", quals), ("offsets", offsets),
+                                                                          ("channel", channel), ("mux", mux), ("start_time", t))})
         # ppqc_submit waits for the slot's previous batch before reusing it, so only the newest batch per slot is held
         L.check(self._lib.ppqc_submit(self._ctx, C.byref(b), int(slot)))
         self._keep[int(slot)] = (bases, quals, offsets, channel, mux, t, ff)
@@ -99,6 +105,8 @@ class QCContext:
         number of records appended.  Channel / start time come from the ch= / start_time= header fields."""
         buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
         n = C.c_uint64()
+        if SUBMIT_HOOK is not None:
+            SUBMIT_HOOK("fastq", {"text": (buf.ctypes.data, buf.nbytes)})
         L.check(self._lib.ppqc_submit_fastq(self._ctx, _ptr(buf) if buf.size else None, int(buf.size), int(slot),
                                             int(mux), C.byref(n)))
         self._keep[int(slot)] = (buf,)
@@ -134,6 +142,11 @@ class QCContext:
     def sync(self):
         L.check(self._lib.ppqc_sync(self._ctx))
         self._keep.clear()
+
+    def slot_wait(self, slot):
+        """Until the host batch of the newest submit on staging slot ``slot`` may be overwritten (its H2D copies are done)."""
+        L.check(self._lib.ppqc_slot_wait(self._ctx, int(slot)))
+        self._keep.pop(int(slot), None)
 
     @property
     def n_reads(self):

@@ -44,7 +44,19 @@ multiread_flag = False
 device = 0
 n_channels = 512
 n_hours = 48
+DIST = None           # (torch.distributed, torch, rank, world) of a `--gpus N` run, set by run(); None on one GPU
 H5_OPEN = None        # HDF5 opener override (default: h5py.File); lets other bindings or tests supply the reader
+
+
+def _h5_opener_from_env():
+    """PYPORE_H5_OPENER="module:callable": an HDF5 opener other than h5py.File for the Fast5 loaders (another binding, or
+    the stand-in of the test suite in the rank processes of a --gpus run, which no monkeypatch reaches)."""
+    spec = os.environ.get("PYPORE_H5_OPENER")
+    if not spec:
+        return None
+    import importlib
+    mod, _, attr = spec.partition(":")
+    return getattr(importlib.import_module(mod), attr)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -157,9 +169,15 @@ def faststats_data(ChannelOut, GCTable=None):
                 min_pos_len=None if int(t["min_pos_len"]) >= I64_MAX else int(t["min_pos_len"]))
 
 
+class GCCounts(list):
+    """The 20 bin counts themselves (the merged gc_hist table of a multi-GPU run) where FastStats takes a GC table."""
+
+
 def gc_histogram(gc_values):
     """20 bins of 5 % over the positive values (``GCVec`` keeps > 0, :136; plotly xbins start 0, size 5, :241).
     ``gc_values`` may be percentages or a (gc_count, length) pair of integer arrays (exact binning)."""
+    if isinstance(gc_values, GCCounts):
+        return [int(x) for x in gc_values]
     if isinstance(gc_values, tuple):
         gc, ln = (np.asarray(a, dtype=np.int64) for a in gc_values)
         sel = gc > 0
@@ -488,64 +506,129 @@ def summary_reader(filein):
                 mean_q=np.asarray(mq, dtype=np.float64), ref_start=ref_start)
 
 
+def dist_rank_world():
+    return (DIST[2], DIST[3]) if DIST is not None else (0, 1)
+
+
+def is_writer():
+    """Rank 0 writes the outputs of a multi-GPU run; every rank holds the merged tables."""
+    return dist_rank_world()[0] == 0
+
+
+def my_share(files):
+    """This rank's contiguous share of the job's files (merge.shard_files; everything on one GPU)."""
+    rank, world = dist_rank_world()
+    files = list(files)
+    if world == 1:
+        return files
+    from .merge import shard_files
+    return shard_files(files, rank, world)
+
+
+def finalize_run(ctx):
+    """Run-level tables of the job: ``ctx.finalize()`` on one GPU, the RCCL merge of every rank's tables otherwise
+    (merge.finalize_distributed: what the reference does by gathering its workers' results over the result queue,
+    lib/seq_routines.py:940-942, and summing over channels in FastStats, :103-108)."""
+    if DIST is None:
+        return ctx.finalize()
+    from .merge import finalize_distributed
+    dist, torch = DIST[0], DIST[1]
+    return finalize_distributed(ctx, dist, torch)
+
+
+def job_min(value):
+    """MIN of a host integer over the ranks (the same value on one GPU)."""
+    if DIST is None:
+        return int(value)
+    from .merge import allreduce_min_int
+    return allreduce_min_int(value, DIST[0], DIST[1])
+
+
 def summary_channel_dict(rows, dev=None):
     """ChannelDict of albacore mode on the GPU: ``localtime(float(x) - ref_start)`` floors the fp64 difference to
     whole seconds (:846), so exactly that integer is handed to the kernels; the hour-of-day + wrap quirk
-    (:847-851) is ``time_mode 1``; there is no mux level (``n_mux = 1``)."""
+    (:847-851) is ``time_mode 1``; there is no mux level (``n_mux = 1``).  With several GPUs every rank takes a
+    contiguous share of the rows (``ref_start`` is the minimum over all of them)."""
     sec = np.floor(rows["start"] - rows["ref_start"]).astype(np.int64)
-    n = len(sec)
     if np.any(rows["channel"] < 1) or np.any(rows["channel"] > n_channels):
         bad = rows["channel"][(rows["channel"] < 1) | (rows["channel"] > n_channels)][0]
         raise IndexError("channel %d outside 1..%d (the reference raises IndexError at lib/seq_routines.py:842)"
                          % (bad, n_channels))
     if np.any(rows["length"] < 0) or np.any(rows["length"] >= (1 << 32)):
         raise ValueError("sequence length outside 0..2^32-1")
+    rank, world = dist_rank_world()
+    a, e = rank * len(sec) // world, (rank + 1) * len(sec) // world
     with qc.QCContext(device=device if dev is None else dev, n_channels=n_channels, n_mux=1, n_time_bins=n_hours,
                       bin_seconds=3600, time_mode=1, tz_offset_s=local_tz_offset(), ref_time_s=0, fail_q=7.0,
-                      max_reads_hint=n) as ctx:
-        ctx.submit_records(rows["length"].astype(np.uint32), rows["mean_q"], rows["channel"].astype(np.uint32),
-                           np.ones(n, np.uint8), sec)
-        tables = ctx.finalize()
+                      max_reads_hint=e - a) as ctx:
+        if e > a:
+            ctx.submit_records(rows["length"][a:e].astype(np.uint32), rows["mean_q"][a:e], rows["channel"][a:e].astype(np.uint32),
+                               np.ones(e - a, np.uint8), sec[a:e])
+        tables = finalize_run(ctx)
     if int(tables["totals"][8]):
         raise KeyError("a read falls in hour bin >= %d (the reference raises KeyError at lib/seq_routines.py:113)" % n_hours)
     return channel_dict_from_tables(tables, summary=True)
 
 
-def _submit_fastq_files(ctx, files, host_meta):
-    """Every file through the GPU tokenizer (ppqc_submit_fastq: the text goes to the card as it is, alternating between
-    the two staging slots).  A text the strict tokenizer refuses (blank lines between records, which SeqIO tolerates)
-    goes through the host packer instead, with ``host_meta(packed, path)`` supplying (channel, mux, time)."""
+def _submit_fastq_files(ctx, files, host_meta, keep=None):
+    """Every file through the GPU tokenizer (ppqc_submit_fastq): a loader thread reads each file straight into a pinned
+    host slot while the previous one is copied and reduced (staging.Stage), the text goes to the card as it is.  A text
+    the strict tokenizer refuses (blank lines between records, which SeqIO tolerates) goes through the host packer
+    instead, with ``host_meta(packed, path)`` supplying (channel, mux, time).  ``keep``: a list that receives
+    (path, packed) of every file, host-packed, for -fq (then every file takes the host packer)."""
     from ._lib import PPQCError
-    for k, path in enumerate(files):
-        text = fastq_io.read_text(path)
-        try:
-            ctx.submit_fastq(text, slot=k % 2, mux=1)
-        except PPQCError as e:
-            if "multiple of 4" not in str(e):
-                raise
-            log.debug("%s: %s; using the host packer" % (path, e))
-            p = fastq_io.pack_fastq(text)
-            if p["n_bad_qual"]:
-                raise ValueError("%s: %d quality characters outside '!'..'~' (SeqIO raises ValueError)" % (path, p["n_bad_qual"]))
-            if p["n_reads"]:
-                ch, mux, t = host_meta(p, path)
-                ctx.submit(p["bases"], p["quals"], p["offsets"], ch, mux, t, None, slot=k % 2)
+    from .staging import Stage
+
+    def fill(path, slot):
+        return path, fastq_io.read_text_into(path, slot)
+
+    def submit(item, d):
+        path, text = item
+        if keep is None:
+            try:
+                ctx.submit_fastq(text, slot=d, mux=1)
+                return True
+            except PPQCError as e:
+                if "multiple of 4" not in str(e):
+                    raise
+                log.debug("%s: %s; using the host packer" % (path, e))
+        p = fastq_io.pack_fastq(text)          # copies out of the pinned text into arrays of its own
+        if p["n_bad_qual"]:
+            raise ValueError("%s: %d quality characters outside '!'..'~' (SeqIO raises ValueError)" % (path, p["n_bad_qual"]))
+        if keep is not None:
+            p["text"] = p["text"].copy()       # the titles are cut out of it after the slot has been refilled
+            keep.append((path, p))
+        if not p["n_reads"]:
+            return False
+        ch, mux, t = host_meta(p, path)
+        ctx.submit(p["bases"], p["quals"], p["offsets"], ch, mux, t, None, slot=d)
+        ctx.slot_wait(d)                       # these arrays are pageable and die with `p`
+        return False
+
+    with Stage(ctx) as stage:
+        stage.run(files, fill, submit)
     e = ctx.input_errors()
     if e["bad_quality_bytes"]:
         raise ValueError("%d quality characters outside '!'..'~' (SeqIO raises ValueError)" % e["bad_quality_bytes"])
 
 
 def fastq_gc(files, dev=None):
-    """``fastq_reader`` over a list of FASTQ files (:40-53): per-record (gc_count, length) from the GPU."""
+    """``fastq_reader`` over a list of FASTQ files (:40-53): per-record (gc_count, length) from the GPU, or -- several
+    GPUs, every rank holding a share of the files -- the merged 20-bin GC histogram (same bins, counted on the device)."""
     with qc.QCContext(device=device if dev is None else dev, n_channels=n_channels, n_mux=1, n_time_bins=n_hours) as ctx:
-        _submit_fastq_files(ctx, files, lambda p, path: (p["channel"], np.ones(p["n_reads"], np.uint8),
-                                                         np.zeros(p["n_reads"], np.int64)))
-        s = ctx.read_stats()
-        extra = ctx.finalize() if ctx.n_reads else None
+        _submit_fastq_files(ctx, my_share(files), lambda p, path: (p["channel"], np.ones(p["n_reads"], np.uint8),
+                                                                   np.zeros(p["n_reads"], np.int64)))
+        if DIST is not None:
+            extra = finalize_run(ctx)
+            gc_table = GCCounts(int(x) for x in extra["gc_hist"])
+        else:
+            s = ctx.read_stats()
+            extra = ctx.finalize() if ctx.n_reads else None
+            gc_table = (s["gc"], s["length"])
     # the reference int()s header field 3 minus its 'ch=' prefix (:51) and dies on anything else
     if extra is not None and int(extra["totals"][7]):
         raise ValueError("%d FASTQ records without a usable ch= header field" % int(extra["totals"][7]))
-    return s["gc"], s["length"], extra
+    return gc_table, extra
 
 
 def summary_module(fqfolder, summary_table_file, size):
@@ -553,10 +636,12 @@ def summary_module(fqfolder, summary_table_file, size):
     files = list(fastq_io.fastq_files(fqfolder))
     rows = summary_reader(summary_table_file)
     ChannelOut = summary_channel_dict(rows)
-    gc, length, seq_tables = fastq_gc(files)
+    gc_table, seq_tables = fastq_gc(files)
     ChannelOut.seq_tables = seq_tables     # bonus: N50 / N count / quality from the sequences themselves
+    if not is_writer():
+        return ChannelOut, None, None
     plates = result_plotting(ChannelOut)
-    stats = FastStats(ChannelOut, (gc, length))
+    stats = FastStats(ChannelOut, gc_table)
     return ChannelOut, stats, plates
 
 
@@ -566,34 +651,29 @@ def summary_module(fqfolder, summary_table_file, size):
 
 def fastq_module(fqfolder, Fast_flag, size):
     """FASTQ files whose albacore headers carry ch= and start_time= (no sequencing_summary.txt, no Fast5): RefTime is
-    the earliest start time.  Without -fq the text is tokenised on the GPU; with -fq the host packer keeps the records
-    for the output file."""
+    the earliest start time of the job.  Without -fq the text is tokenised on the GPU; with -fq the host packer keeps the
+    records for the output file."""
     files = list(fastq_io.fastq_files_any(fqfolder))
     if not files:
         log.error("no FASTQ file under %s" % fqfolder)
         sys.exit(1)
-    packed, per_read = [], None
+    packed = [] if Fast_flag else None
     with qc.QCContext(device=device, n_channels=n_channels, n_mux=4, n_time_bins=n_hours, bin_seconds=3600,
                       time_mode=1, tz_offset_s=0, ref_time_s=0, fail_q=7.0) as ctx:
         def meta(p, path):
             return p["channel"], np.ones(p["n_reads"], np.uint8), p["start_time"]   # no mux in FASTQ headers: mux 1
-        if Fast_flag:
-            for k, path in enumerate(files):
-                p = fastq_io.pack_fastq(fastq_io.read_text(path))
-                if p["n_bad_qual"]:
-                    raise ValueError("%s: %d quality characters outside '!'..'~'" % (path, p["n_bad_qual"]))
-                packed.append((path, p))
-                if p["n_reads"]:
-                    ctx.submit(p["bases"], p["quals"], p["offsets"], *meta(p, path), None, slot=k % 2)
-            per_read = ctx.read_stats()
-        else:
-            _submit_fastq_files(ctx, files, meta)
+        _submit_fastq_files(ctx, my_share(files), meta, keep=packed)
+        per_read = ctx.read_stats() if Fast_flag else None
         ctx.finalize_extremes()
         tmin, tmax = ctx.time_range()            # over the reads that have a start time
-        ctx.set_ref_time(tmin if tmin <= tmax else 0)
-        ctx.finalize_tables()
-        ctx.finalize_n50()
-        tables = ctx.fetch_tables()
+        tmin = job_min(tmin)
+        ctx.set_ref_time(tmin if tmin != I64_MAX else 0)
+        if DIST is None:
+            ctx.finalize_tables()
+            ctx.finalize_n50()
+            tables = ctx.fetch_tables()
+        else:
+            tables = finalize_run(ctx)
     if int(tables["totals"][7]):
         raise ValueError("%d FASTQ records without a usable ch= header field" % int(tables["totals"][7]))
     if int(tables["totals"][11]):
@@ -601,31 +681,57 @@ def fastq_module(fqfolder, Fast_flag, size):
     ChannelOut = channel_dict_from_tables(tables)
     if Fast_flag:
         from . import fastq_out
-        fastq_out.write_passing(packed, per_read, os.path.join(work_dir, out_dir, prefix + '.fastq.gz'))
+        _write_fastq(lambda path: fastq_out.write_passing(packed, per_read, path, n_channels=n_channels, part=DIST is not None))
+    if not is_writer():
+        return ChannelOut, None, None
     plates = result_plotting(ChannelOut)
     stats = FastStats(ChannelOut)
     return ChannelOut, stats, plates
+
+
+def _write_fastq(write_part):
+    """``<label>.fastq.gz``: written at once on one GPU; with several, every rank writes its passing reads as a part
+    whose BGZF blocks end with each channel, and rank 0 puts the parts together channel by channel, ranks in order --
+    the reference's own scheme (one BGZF file per channel, concatenated in channel order, lib/seq_routines.py:798-816)."""
+    from . import fastq_out
+    final = os.path.join(work_dir, out_dir, prefix + '.fastq.gz')
+    if DIST is None:
+        write_part(final)
+        return
+    dist, _torch, rank, world = DIST
+    write_part(final + '.part%d' % rank)
+    dist.barrier()
+    if rank == 0:
+        fastq_out.stitch_parts([final + '.part%d' % r for r in range(world)], final, n_channels)
+    dist.barrier()
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # Fast5 modes: h5py loaders on the CPU pack CSR batches (lib/seq_routines.py:903-1029)
 # ---------------------------------------------------------------------------------------------------------------
 
-def _tables_from_loader(batches, ref_time, Fast_flag, compat_flags=0):
+def _tables_from_loader(record_batches, ref_time, Fast_flag, compat_flags=0):
+    """``record_batches``: iterable of lists of loader records.  A loader thread packs each list straight into a pinned
+    host slot (staging.pack_records) while the previous batch is copied and reduced."""
+    from .staging import Stage, pack_records
+    kept = []
     with qc.QCContext(device=device, n_channels=n_channels, n_mux=4, n_time_bins=n_hours, bin_seconds=3600,
                       time_mode=1, tz_offset_s=local_tz_offset(), ref_time_s=int(ref_time), fail_q=7.0,
                       compat_flags=compat_flags) as ctx:
-        kept = []
-        for k, b in enumerate(batches):
-            if b["n_reads"] == 0:
-                continue
-            ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["start_time"], b["fail_flag"],
-                       slot=k % 2)
-            if Fast_flag:
-                kept.append(b)
+        def fill(recs, slot):
+            return pack_records(recs, slot) if recs else None
+
+        def submit(b, d):
+            ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["start_time"], b["fail_flag"], slot=d)
+            if Fast_flag:   # -fq keeps the reads: out of the pinned slot, which is about to be refilled
+                kept.append({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in b.items()})
+            return True
+
+        with Stage(ctx) as stage:
+            stage.run(record_batches, fill, submit)
         ctx.sync()
         per_read = ctx.read_stats() if Fast_flag else None
-        tables = ctx.finalize()
+        tables = finalize_run(ctx)
     return tables, per_read, kept
 
 
@@ -633,19 +739,22 @@ def fast5module(work_dir_, file_folder, prefix_, tmp_dir, Fast_flag, size, h5_op
     """Single-read Fast5 (lib/seq_routines.py:903-948): files are bucketed by the channel in their name (:909-911),
     RefTime is the smallest exp_start_time of the first file of each leaf directory (:819-828, 882-893)."""
     from . import fast5_reader as f5r
-    h5_open = h5_open or H5_OPEN
+    h5_open = h5_open or H5_OPEN or _h5_opener_from_env()
     files, ref_time = f5r.dir_surfer(file_folder, h5_open=h5_open)
     if ref_time is None:
         log.error("no Fast5 file under %s" % file_folder)
         sys.exit(1)
-    batches = f5r.load_batches(files, n_channels, threads=size, h5_open=h5_open)
+    batches = f5r.iter_record_batches(my_share(files), n_channels, threads=size, h5_open=h5_open)
     tables, per_read, kept = _tables_from_loader(batches, ref_time, Fast_flag)
-    for c in np.nonzero(tables["chan_reads"] == 0)[0]:
-        log.warning('Channel %s inactive!' % int(c))
+    if is_writer():
+        for c in np.nonzero(tables["chan_reads"] == 0)[0]:
+            log.warning('Channel %s inactive!' % int(c))
     ChannelOut = channel_dict_from_tables(tables)
     if Fast_flag:
         from . import fastq_out
-        fastq_out.write_passing_batches(kept, per_read, os.path.join(work_dir, out_dir, prefix + '.fastq.gz'))
+        _write_fastq(lambda path: fastq_out.write_passing_batches(kept, per_read, path, n_channels=n_channels, part=DIST is not None))
+    if not is_writer():
+        return ChannelOut, None, None
     plates = result_plotting(ChannelOut)
     stats = FastStats(ChannelOut)
     return ChannelOut, stats, plates
@@ -656,19 +765,31 @@ def multifast5reader(work_dir_, file_folder, prefix_, tmp_dir, Fast_flag, size, 
     tracking_id/exp_start_time (lib/multi_read_fast5_reader.py:137).  Every file is counted (the reference drops one
     file's reads through ``for r in range(en)``, :985, and never fills read_lists for -fq; neither defect is kept)."""
     from . import multi_read_fast5_reader as mf5r
-    h5_open = h5_open or H5_OPEN
+    h5_open = h5_open or H5_OPEN or _h5_opener_from_env()
     files = mf5r.dir_surfer(file_folder)
-    batches, ref_start = mf5r.load_batches(files, threads=size, h5_open=h5_open)
+    ref_start = mf5r.ref_start_of(files, h5_open)        # every rank reads it from the job's first file
+    batches = mf5r.iter_record_batches(my_share(files), threads=size, h5_open=h5_open)
     # channel_parser takes the read of a single-read channel under every mux (lib/multi_read_fast5_reader.py:64-67):
-    # reproduced, so that the tables are the reference's (PPQC_COMPAT_MULTI_READ_SINGLE; fast5module has no such branch)
+    # reproduced, so that the tables are the reference's (PPQC_COMPAT_MULTI_READ_SINGLE; fast5module has no such branch).
+    # The rule looks at a channel's read count in the whole job, which one rank of several does not know: a multi-GPU
+    # run counts such a read under its own mux only and says so.
     from ._lib import COMPAT_MULTI_READ_SINGLE
-    tables, per_read, kept = _tables_from_loader(batches, ref_start, Fast_flag, COMPAT_MULTI_READ_SINGLE)
-    for c in np.nonzero(tables["chan_reads"] == 0)[0]:
-        log.warning('Channel %s inactive!' % int(c))
+    compat = COMPAT_MULTI_READ_SINGLE
+    if DIST is not None:
+        compat = 0
+        if is_writer():
+            log.warning("--gpus > 1: the single-read-channel rule of channel_parser (a channel's only read counted under "
+                        "every mux) is not applied; run on one GPU for tables identical to the reference's in that case")
+    tables, per_read, kept = _tables_from_loader(batches, ref_start or 0, Fast_flag, compat)
+    if is_writer():
+        for c in np.nonzero(tables["chan_reads"] == 0)[0]:
+            log.warning('Channel %s inactive!' % int(c))
     ChannelOut = channel_dict_from_tables(tables)
     if Fast_flag:
         from . import fastq_out
-        fastq_out.write_passing_batches(kept, per_read, os.path.join(work_dir, out_dir, prefix + '.fastq.gz'))
+        _write_fastq(lambda path: fastq_out.write_passing_batches(kept, per_read, path, n_channels=n_channels, part=DIST is not None))
+    if not is_writer():
+        return ChannelOut, None, None
     plates = result_plotting(ChannelOut)
     stats = FastStats(ChannelOut)
     return ChannelOut, stats, plates
@@ -681,12 +802,43 @@ def _lit(s, default=None):
         return default
 
 
+def init_distributed(gpus, dev):
+    """One process per GPU (started by seqstats.launch_ranks / torchrun: RANK, LOCAL_RANK, WORLD_SIZE in the
+    environment), torch.distributed over RCCL.  Returns the device this rank computes on.  PPQC_DIST_BACKEND=gloo keeps
+    every rank on the device given with -g: the two-ranks-on-one-GPU rehearsal of the test suite (RCCL refuses two
+    ranks on one device)."""
+    global DIST
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != gpus:
+        log.error("--gpus %d but WORLD_SIZE is %d" % (gpus, world))
+        sys.exit(2)
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("PPQC_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl":
+        if n_dev < world:
+            log.error("--gpus %d but this node shows %d GPU(s)" % (gpus, n_dev))
+            sys.exit(3)
+        dev = local
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    DIST = (dist, torch, rank, world)
+    return dev
+
+
 def run(arguments):
     """lib/seq_routines.py:1075-1111: the positional list of strings built by seqstats.ArgsReader
     ``[work_dir, file_folder, prefix, out_dir, ver, Fast_flag, size, summary_flag, albacore_file, multiread_flag]``
     (booleans and the -a list as their ``str()``), plus the optional GPU-path extras
-    ``[device, input_format, channels, hours]``."""
-    global summary_flag, work_dir, prefix, out_dir, multiread_flag, device, n_channels, n_hours
+    ``[device, input_format, channels, hours, gpus]``."""
+    global summary_flag, work_dir, prefix, out_dir, multiread_flag, device, n_channels, n_hours, DIST
     if not len(arguments) > 4:
         sys.exit(1)
     work_dir, file_folder, prefix, out_dir, ver = arguments[0], arguments[1], arguments[2], arguments[3], arguments[4]
@@ -699,15 +851,24 @@ def run(arguments):
     input_format = arguments[11] if len(arguments) > 11 else 'fast5'
     n_channels = int(arguments[12]) if len(arguments) > 12 else 512
     n_hours = int(arguments[13]) if len(arguments) > 13 else 48
+    gpus = int(arguments[14]) if len(arguments) > 14 else 1
     log.info('Start Main Parser')
     verbosity(_lit(ver, 1) if isinstance(ver, str) else ver)
     os.makedirs(os.path.join(work_dir, out_dir), exist_ok=True)
-    if summary_flag:
-        summary_table = _lit(arguments[8])
-        summary_table = summary_table[0] if isinstance(summary_table, (list, tuple)) else arguments[8]
-        return summary_module(file_folder, summary_table, size)
-    if input_format == 'fastq':
-        return fastq_module(file_folder, Fast_flag, size)
-    if not multiread_flag:
-        return fast5module(work_dir, file_folder, prefix, tmp_dir, Fast_flag, size)
-    return multifast5reader(work_dir, file_folder, prefix, tmp_dir, Fast_flag, size)
+    DIST = None
+    if gpus > 1:
+        device = init_distributed(gpus, device)
+    try:
+        if summary_flag:
+            summary_table = _lit(arguments[8])
+            summary_table = summary_table[0] if isinstance(summary_table, (list, tuple)) else arguments[8]
+            return summary_module(file_folder, summary_table, size)
+        if input_format == 'fastq':
+            return fastq_module(file_folder, Fast_flag, size)
+        if not multiread_flag:
+            return fast5module(work_dir, file_folder, prefix, tmp_dir, Fast_flag, size)
+        return multifast5reader(work_dir, file_folder, prefix, tmp_dir, Fast_flag, size)
+    finally:
+        if DIST is not None:
+            DIST[0].destroy_process_group()
+            DIST = None

@@ -4,7 +4,10 @@
 Options added for the GPU path (they do not change any existing one): ``-g/--gpu_device`` (HIP device index),
 ``-f/--input_format`` (``fast5`` as in the reference, or ``fastq`` to read FASTQ files whose albacore headers carry
 ``ch=`` / ``start_time=`` without a sequencing_summary.txt), ``--channels`` and ``--hours`` (table sizes; 512 and 48
-are hard-coded in the reference, lib/seq_routines.py:99,833)."""
+are hard-coded in the reference, lib/seq_routines.py:99,833) and ``--gpus N``: N processes, one per GPU, each over a
+contiguous share of the input files, their tables merged over RCCL -- what ``-n`` is to the reference's pool of worker
+processes (lib/seqstats.py:111-112, lib/seq_routines.py:916-923); ``-n`` itself stays the number of loader threads of
+each process."""
 from __future__ import annotations
 
 import argparse
@@ -68,6 +71,7 @@ def build_parser(default_dir):
 -f,  --input_format                fast5 | fastq (FASTQ files with albacore headers) [fast5]
      --channels                    number of flow-cell channels [512]
      --hours                       number of hourly bins [48]
+     --gpus                        number of GPUs, one process each [1]
 -h,  --help                        show this help message and exit
 ''')
     f.add_argument('-fq', '--fastq', action="store", nargs=1, metavar='', choices=['y', 'n', 'yes', 'no'],
@@ -86,6 +90,7 @@ def build_parser(default_dir):
                    help=argparse.SUPPRESS)
     f.add_argument('--channels', action="store", type=int, default=512, metavar='', help=argparse.SUPPRESS)
     f.add_argument('--hours', action="store", type=int, default=48, metavar='', help=argparse.SUPPRESS)
+    f.add_argument('--gpus', action="store", type=int, default=1, metavar='', help=argparse.SUPPRESS)
     return parser
 
 
@@ -100,9 +105,33 @@ def ArgsReader(args):
     ags = [work_dir, args.input_directory, args.label, out_dir, str(args.verbose), str(fastq_flag),
            str(args.threads_number), str(summary_flag), str(albacore_file), str(multi_read_flag),
            # extras of the GPU path (absent = defaults, so a reference-shaped 10-element list still works)
-           str(args.gpu_device), args.input_format, str(args.channels), str(args.hours)]
+           str(args.gpu_device), args.input_format, str(args.channels), str(args.hours), str(args.gpus)]
     from . import seq_routines as sq
     return sq.run(ags)
+
+
+def launch_ranks(gpus, argsin):
+    """``--gpus N`` started plainly: N rank processes as ONE torchrun child (``python -m torch.distributed.run
+    --nproc-per-node N -m pypore_amd.pypore seqstats ...``), decided before this process has imported torch or touched
+    HIP.  A child process, never an exec of this one; its exit code is ours, so a rank that fails fails the command."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "pypore_amd.pypore", "seqstats"] + list(argsin)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        log.error("the %d-rank run failed (exit code %d)" % (gpus, rc))
+        sys.exit(rc if rc > 0 else 1)
+    return None
 
 
 def run(argsin):
@@ -116,6 +145,11 @@ def run(argsin):
             parser.print_help()
             log.error('Missing mandatory arguments!')
             sys.exit(1)
+        if args.gpus < 1:
+            log.error('--gpus must be at least 1')
+            sys.exit(1)
+        if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            return launch_ranks(args.gpus, argsin)     # nothing here has touched torch or the GPU
         return ArgsReader(args)
     except IOError as msg:
         parser.error(str(msg))

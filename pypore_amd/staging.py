@@ -1,0 +1,185 @@
+"""Pinned, overlapped staging between the loaders and the GPU (BASELINE.json north_star: "loaders that pack reads into
+a CSR layout of pinned buffers, double-buffered H2D").
+
+The reference's loaders hand every read to a worker as Python strings (lib/fast5_reader.py:36-71,
+lib/multi_read_fast5_reader.py:121-147, lib/seq_routines.py:896-901) and its pool pulls the next task while earlier
+results are merged (:916-942).  Here a loader thread writes each batch STRAIGHT into page-locked host memory
+(``ppqc_alloc_pinned``), as the CSR arrays ``ppqc_submit`` takes or as FASTQ text for ``ppqc_submit_fastq``, while the main
+thread hands the previous batch to the library: three host slots over the library's two device staging slots, so that one
+slot is being filled, one is being copied and one has its kernels running.  A host slot goes back to the loader when
+``ppqc_slot_wait`` says its copies are done.  No statistics are computed here."""
+from __future__ import annotations
+
+import queue
+import threading
+import weakref
+
+import numpy as np
+
+from . import qc
+
+LIVE_SLOTS = weakref.WeakSet()   # every PinnedSlot alive (tests ask whether a pointer handed to the library lies in one)
+
+
+def in_pinned_slot(address, nbytes=1):
+    return any(s.owns(address, nbytes) for s in list(LIVE_SLOTS))
+
+
+class PinnedSlot:
+    """One host slot: three page-locked arenas (bases / text, qualities, per-read metadata) that grow on demand and are
+    reused from batch to batch."""
+
+    def __init__(self):
+        self._b = self._q = self._m = None
+        LIVE_SLOTS.add(self)
+
+    @staticmethod
+    def _ensure(buf, nbytes):
+        if buf is not None and buf.nbytes >= nbytes:
+            return buf
+        if buf is not None:
+            buf.close()
+        return qc.PinnedBuffer(max(4096, nbytes + nbytes // 2))
+
+    def csr(self, n_bytes, n_reads):
+        """Views {bases, quals, offsets, start_time, channel, mux, fail_flag} for a batch of this size."""
+        self._b = self._ensure(self._b, n_bytes)
+        self._q = self._ensure(self._q, n_bytes)
+        need = 8 * (n_reads + 1) + 8 * n_reads + 4 * n_reads + 2 * n_reads
+        self._m = self._ensure(self._m, need)
+        m, o = self._m.array, 0
+
+        def take(nb, dt):
+            nonlocal o
+            v = m[o:o + nb].view(dt)
+            o += nb
+            return v
+        return dict(bases=self._b.array[:n_bytes], quals=self._q.array[:n_bytes], offsets=take(8 * (n_reads + 1), np.uint64),
+                    start_time=take(8 * n_reads, np.int64), channel=take(4 * n_reads, np.uint32),
+                    mux=take(n_reads, np.uint8), fail_flag=take(n_reads, np.uint8))
+
+    def text(self, n_bytes):
+        self._b = self._ensure(self._b, n_bytes)
+        return self._b.array[:n_bytes]
+
+    def text_capacity(self):
+        return 0 if self._b is None else self._b.nbytes
+
+    def owns(self, address, nbytes=1):
+        for buf in (self._b, self._q, self._m):
+            if buf is not None and buf.array is not None:
+                base = buf.array.ctypes.data
+                if base <= address and address + nbytes <= base + buf.nbytes:
+                    return True
+        return False
+
+    def close(self):
+        for buf in (self._b, self._q, self._m):
+            if buf is not None:
+                buf.close()
+        self._b = self._q = self._m = None
+
+
+def pack_records(recs, slot=None):
+    """CSR batch from loader records ``(channel, mux, start_time, fail, title, bases, quals)`` -- into the pinned slot's
+    arenas when one is given (each read is copied once, from the bytes h5py returned into page-locked memory), else
+    into fresh arrays."""
+    n = len(recs)
+    lens = np.fromiter((len(r[5]) for r in recs), np.int64, n)
+    nb = int(lens.sum())
+    if slot is not None:
+        v = slot.csr(nb, n)
+    else:
+        v = dict(bases=np.empty(nb, np.uint8), quals=np.empty(nb, np.uint8), offsets=np.empty(n + 1, np.uint64),
+                 start_time=np.empty(n, np.int64), channel=np.empty(n, np.uint32), mux=np.empty(n, np.uint8),
+                 fail_flag=np.empty(n, np.uint8))
+    off = v["offsets"]
+    off[0] = 0
+    if n:
+        np.cumsum(lens, out=off[1:].view(np.int64))
+    b, q, o = v["bases"], v["quals"], 0
+    for r, ln in zip(recs, lens):
+        if ln:
+            b[o:o + ln] = np.frombuffer(r[5], np.uint8)
+            q[o:o + ln] = np.frombuffer(r[6], np.uint8)
+            o += ln
+    v["channel"][:] = [r[0] for r in recs]
+    v["mux"][:] = [r[1] for r in recs]
+    v["start_time"][:] = [r[2] for r in recs]
+    v["fail_flag"][:] = [r[3] for r in recs]
+    v["n_reads"] = n
+    v["titles"] = [r[4] for r in recs]
+    return v
+
+
+class Stage:
+    """Loader thread + pinned host slots.  ``fill(job, slot)`` runs on the loader thread and returns the item to submit
+    (or None to skip the job); ``submit(item, device_slot)`` runs on the caller's thread and must hand the item to
+    ``ctx.submit`` / ``ctx.submit_fastq`` with that staging slot (or not touch the GPU at all)."""
+
+    N_HOST_SLOTS = 3
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.slots = [PinnedSlot() for _ in range(self.N_HOST_SLOTS)]
+
+    def run(self, jobs, fill, submit):
+        free, ready = queue.Queue(), queue.Queue()
+        for k in range(len(self.slots)):
+            free.put(k)
+        stop = threading.Event()
+
+        def loader():
+            try:
+                for job in jobs:
+                    k = free.get()
+                    if stop.is_set():
+                        return
+                    item = fill(job, self.slots[k])
+                    if item is None:
+                        free.put(k)
+                        continue
+                    ready.put((k, item))
+                ready.put(None)
+            except BaseException as e:      # handed to the caller's thread
+                ready.put(e)
+
+        th = threading.Thread(target=loader, name="ppqc-loader", daemon=True)
+        th.start()
+        in_flight, n = [], 0
+        try:
+            while True:
+                got = ready.get()
+                if got is None:
+                    break
+                if isinstance(got, BaseException):
+                    raise got
+                k, item = got
+                d = n % 2
+                used = submit(item, d)
+                n += 1
+                if used is False:           # the submit did not use the GPU slot: the host slot is free at once
+                    n -= 1
+                    free.put(k)
+                    continue
+                in_flight.append((k, d))
+                if len(in_flight) >= 2:     # the older batch's copies: done, or about to be (its slot is the other one)
+                    k0, d0 = in_flight.pop(0)
+                    self.ctx.slot_wait(d0)
+                    free.put(k0)
+        finally:
+            stop.set()
+            free.put(0)                     # wakes a loader that waits for a slot
+            th.join()
+        for _k, d in in_flight:
+            self.ctx.slot_wait(d)
+
+    def close(self):
+        for s in self.slots:
+            s.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -45,6 +45,59 @@ def _check_stats(got, want):
         assert got[k] == want[k], (k, got[k], want[k])
 
 
+def _plot_data(html_path):
+    """The traces plotly wrote into an HTML file: the first JSON array behind ``Plotly.newPlot(``."""
+    import json
+    text = open(html_path).read()
+    k = text.rindex("Plotly.newPlot(")       # the page also carries plotly.js itself, which has the words too
+    k = text.index("[", k)
+    data, _ = json.JSONDecoder().raw_decode(text[k:])
+    return data, text
+
+
+def _check_html_contract(res_dir, label, stats, per, n_channels=512):
+    """What the reference's injected JavaScript and its readers rely on (lib/seq_routines.py:84, 207, 306-308): the trace
+    names, the number of per-channel traces, and the summary table's cells."""
+    data, text = _plot_data(os.path.join(res_dir, label + "_sequencing_summary.html"))
+    names = [t.get("name") for t in data]
+    for n in ("ReadsPerHour", "BasesPerHour", "MeanReadLengthPerHour"):
+        assert names.count(n) == 1, (n, names)
+        assert "divname == '%s'" % n in text                     # the hover glue keys on exactly these names
+    tr = {t["name"]: t for t in data if t.get("name") in ("ReadsPerHour", "BasesPerHour", "MeanReadLengthPerHour")}
+    assert [int(v) for v in tr["ReadsPerHour"]["y"]] == [v[0] for v in stats["HoursDict"]]
+    assert [int(v) for v in tr["BasesPerHour"]["y"]] == [v[1] for v in stats["HoursDict"]]
+    assert [float(v) for v in tr["MeanReadLengthPerHour"]["y"]] == [float(v[2]) for v in stats["HoursDict"]]
+    tables = [t for t in data if t.get("type") == "table"]
+    assert len(tables) == 1
+    cells = [c[0] if isinstance(c, list) else c for c in tables[0]["cells"]["values"]]
+    num = lambda v: None if v is None else float(v)
+    assert [num(c) for c in cells] == [num(v) for v in stats["table"]], (cells, stats["table"])
+    data2, text2 = _plot_data(os.path.join(res_dir, label + "_pore_activity_map.html"))
+    names2 = [t.get("name") for t in data2]
+    assert names2[:2] == ["ReadNHeat", "BaseNHeat"] and data2[0]["type"] == "heatmap"
+    assert len(data2) == 2 + per * n_channels
+    if per == 10:
+        for k in range(1, 5):
+            assert names2.count("Pore%d" % k) == 2 * n_channels
+            assert "divname == 'Pore%d'" % k in text2
+    else:
+        assert names2.count("Channel") == 2 * n_channels and "divname == 'Channel'" in text2
+    assert names2.count("Fail") == n_channels and names2.count("Pass") == n_channels
+    return data, data2
+
+
+class _PinnedWatch:
+    """qc.SUBMIT_HOOK: every host batch handed to ppqc_submit / ppqc_submit_fastq, and whether all of its arrays lie in
+    page-locked staging slots (north_star: loaders pack into pinned buffers)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __call__(self, kind, arrays):
+        from pypore_amd import staging
+        self.calls.append((kind, all(staging.in_pinned_slot(a, n) for a, n in arrays.values() if n)))
+
+
 def _mean_q(qual):
     return po.mean_q_from_fixed(po.err_sum_fixed(qual), len(qual)) if qual else 0.0
 
@@ -70,7 +123,11 @@ def test_albacore_mode_end_to_end(tmp_path, monkeypatch):
     table = tmp_path / "sequencing_summary.txt"
     table.write_text("\n".join(lines) + "\n")
     monkeypatch.chdir(tmp_path)
+    from pypore_amd import qc
+    watch = _PinnedWatch()
+    monkeypatch.setattr(qc, "SUBMIT_HOOK", watch)
     cd, stats, plates = seqstats.run(["-i", str(tmp_path / "fq"), "-l", "alb", "-a", str(table), "-n", "3", "-o", "res"])
+    assert [c for c in watch.calls] == [("fastq", True), ("fastq", True)]      # both files: text read into pinned slots
     ref_cd, _ = po.summary_reader(lines, n_channels=512, tz_offset_s=sq.local_tz_offset())
     gc_list = po.fastq_reader(texts[0]) + po.fastq_reader(texts[1])     # order is irrelevant to every consumer
     want = po.FastStats_data(ref_cd, GCTable=gc_list)
@@ -88,6 +145,7 @@ def test_albacore_mode_end_to_end(tmp_path, monkeypatch):
     assert cd.seq_tables["n50"] == po.n50([len(r["seq"]) for r in recs])
     for f in ("alb_sequencing_summary.html", "alb_pore_activity_map.html"):
         assert (tmp_path / "res" / f).stat().st_size > 10000
+    _check_html_contract(str(tmp_path / "res"), "alb", stats, per=4)
 
 
 def _ref_shaped(recs, ref, tz, n_ch=512, times=None, multi_read_single_quirk=False):
@@ -158,8 +216,13 @@ def test_fast5_modes_on_stand_in_hdf5(tmp_path, monkeypatch):
     ref = f5r.mktime_local(exp)
     times = [int(f5r.mktime_local(_iso(base, r["sec"]))) for r in recs]
     ref_cd = _ref_shaped(recs, ref, sq.local_tz_offset(), times=times)
+    from pypore_amd import qc
+    watch = _PinnedWatch()
+    monkeypatch.setattr(qc, "SUBMIT_HOOK", watch)
     cd, stats, plates = sq.run([str(tmp_path), str(tmp_path / "s"), "one", "res1", "1", "True", "2", "False", "None", "False"])
+    assert watch.calls and all(c == ("csr", True) for c in watch.calls)       # CSR batches packed in pinned slots
     _check_stats(stats, po.FastStats_data(ref_cd))
+    _check_html_contract(str(tmp_path / "res1"), "one", stats, per=10)
     assert plates == po.result_plotting_data(ref_cd)
     for c in range(1, 513):
         assert sq.channel_plot_data(c, cd) == po.ChannelPlotter_data(c, ref_cd)
@@ -195,3 +258,89 @@ def test_fast5_modes_on_stand_in_hdf5(tmp_path, monkeypatch):
         if e:
             assert tuple(e[:3]) == tuple(r[:3]), (c, e[:3], r[:3])
         assert sq.channel_plot_data(c, cd2) == po.ChannelPlotter_data(c, ref_cd_m)
+
+
+def _run_cli(args, cwd, extra_env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests"), env.get("PYTHONPATH", "")])
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, "-m", "pypore_amd.pypore", "seqstats"] + args, cwd=cwd, env=env,
+                       capture_output=True, text=True, timeout=280)
+    return r
+
+
+def test_cli_gpus_2_equals_one_process(tmp_path):
+    """`pypore seqstats --gpus 2` started plainly: the CLI starts its two rank processes itself (torchrun child), every
+    rank takes a contiguous share of the files, the tables are merged by finalize_distributed (time_mode 1 across ranks:
+    every channel's reads are on both) and rank 0 writes the outputs.  Two ranks on the ONE GPU of the test box, so over
+    gloo (PPQC_DIST_BACKEND; RCCL refuses two ranks on a device).  Everything written must equal the one-process run:
+    every trace of both HTML files, and the decompressed <label>.fastq.gz byte for byte."""
+    base = 1_528_000_000
+    recs = _records(11, 900)
+    for r in recs:
+        r["mux"] = 1
+    (tmp_path / "in").mkdir()
+    cuts = [0, 200, 450, 460, 900]
+    for k in range(4):
+        (tmp_path / "in" / ("f%d.fastq" % k)).write_bytes(_fastq_text(recs[cuts[k]:cuts[k + 1]], base))
+    gloo = {"PPQC_DIST_BACKEND": "gloo"}
+    for label, extra in (("g1", []), ("g2", ["--gpus", "2"])):
+        r = _run_cli(["-i", str(tmp_path / "in"), "-l", label, "-f", "fastq", "-fq", "yes", "-o", "res_" + label] + extra,
+                     str(tmp_path), gloo)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    a = gzip.decompress((tmp_path / "res_g1" / "g1.fastq.gz").read_bytes())
+    b = gzip.decompress((tmp_path / "res_g2" / "g2.fastq.gz").read_bytes())
+    assert a == b and a.count(b"\n+\n") > 300
+    assert not [f for f in os.listdir(tmp_path / "res_g2") if ".part" in f]
+    for f in ("_sequencing_summary.html", "_pore_activity_map.html"):
+        d1, _ = _plot_data(str(tmp_path / "res_g1" / ("g1" + f)))
+        d2, _ = _plot_data(str(tmp_path / "res_g2" / ("g2" + f)))
+        assert d1 == d2, f
+    # albacore mode: rows of the table and FASTQ files both shared out over the ranks
+    (tmp_path / "fq" / "pass").mkdir(parents=True)
+    for k in range(3):
+        (tmp_path / "fq" / "pass" / ("p%d.fastq" % k)).write_bytes(_fastq_text(recs[300 * k:300 * (k + 1)], base))
+    hdr = "filename read_id run_id channel start_time duration num_events passes_filtering template_start " \
+          "num_events_template template_duration num_called_template sequence_length_template mean_qscore_template " \
+          "strand_score_template calibration_strand_genome_template a b c"
+    lines = [hdr]
+    for r in recs:
+        core = [str(r["ch"]), repr(r["sec"] + 0.5), "1.0", str(len(r["seq"])), "True", "0.0", "10", "%.3f" % _mean_q(r["qual"])]
+        lines.append(" ".join(["f", "read%d" % r["i"], "u"] + core + ["p1", "p2", "p3", "p4", "p5"]))
+    (tmp_path / "summary.txt").write_text("\n".join(lines) + "\n")
+    for label, extra in (("a1", []), ("a2", ["--gpus", "2"])):
+        r = _run_cli(["-i", str(tmp_path / "fq"), "-l", label, "-a", str(tmp_path / "summary.txt"), "-o", "res_" + label] + extra,
+                     str(tmp_path), gloo)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    for f in ("_sequencing_summary.html", "_pore_activity_map.html"):
+        d1, _ = _plot_data(str(tmp_path / "res_a1" / ("a1" + f)))
+        d2, _ = _plot_data(str(tmp_path / "res_a2" / ("a2" + f)))
+        assert d1 == d2, f
+    # single-read Fast5 through the stand-in HDF5 (PYPORE_H5_OPENER reaches the rank processes), with -fq
+    exp = _iso(base, -20)
+    for sub in ("s/pass/0", "s/fail/0"):
+        (tmp_path / sub).mkdir(parents=True)
+    for r in _records(12, 240, hours=40):
+        fail = r["i"] % 7 == 0
+        d = tmp_path / ("s/fail/0" if fail else "s/pass/0")
+        fq = None if fail else "@read%d\n%s\n+\n%s\n" % (r["i"], r["seq"].decode(), r["qual"].decode())
+        fake_h5.write_single(str(d / ("x_read_%d_ch_%d_strand.fast5" % (r["i"], r["ch"]))), r["i"], r["ch"], r["mux"],
+                             _iso(base, r["sec"]), exp, fq)
+    h5 = dict(gloo, PYPORE_H5_OPENER="fake_h5:FakeH5")
+    for label, extra in (("s1", []), ("s2", ["--gpus", "2"])):
+        r = _run_cli(["-i", str(tmp_path / "s"), "-l", label, "-fq", "yes", "-n", "2", "-o", "res_" + label] + extra,
+                     str(tmp_path), h5)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    for f in ("_sequencing_summary.html", "_pore_activity_map.html"):
+        d1, _ = _plot_data(str(tmp_path / "res_s1" / ("s1" + f)))
+        d2, _ = _plot_data(str(tmp_path / "res_s2" / ("s2" + f)))
+        assert d1 == d2, f
+    assert gzip.decompress((tmp_path / "res_s1" / "s1.fastq.gz").read_bytes()) == \
+        gzip.decompress((tmp_path / "res_s2" / "s2.fastq.gz").read_bytes())
+    # a rank count the launcher cannot give must fail loudly, not run on fewer ranks
+    r = _run_cli(["-i", str(tmp_path / "in"), "-l", "bad", "-f", "fastq", "--gpus", "2"], str(tmp_path),
+                 {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stdout + r.stderr)
