@@ -177,6 +177,8 @@ def timed_blocks(step, fence, steps, min_seconds, reduce_max):
 def main():
     a = parse()
     world_env = os.environ.get("WORLD_SIZE")
+    if a.cli and world_env is None:
+        return cli_mode(a)              # the command under test starts its own ranks (`pypore seqstats --gpus N`)
     if world_env is None and a.gpus > 1:
         return launch_ranks(a)          # nothing below has run: no torch import, no HIP call in this process
     world = int(world_env or "1")
@@ -403,7 +405,75 @@ def config3_sharded(a, torch, dist, qc, synth, finalize_distributed, dev, local,
 
 
 def cli_mode(a):
-    raise SystemExit("bench.py --cli: not implemented yet")
+    """Wall clock of the drop-in itself: `pypore seqstats -i DIR -l bench -f fastq` (a child process: interpreter start,
+    imports, loader thread reading every file into pinned slots, GPU tokenizer + kernels, tables, both HTML reports)
+    over a synthetic directory of albacore-style FASTQ files on tmpfs, beside the reference-shaped Python
+    (oracle/cli_leg.py) on a bounded sample of the same files.  Not the headline metric: the CLI is bound by reading
+    the files and by PCIe, two orders of magnitude below the kernel's roofline."""
+    import shutil
+    import subprocess
+    import tempfile
+    from pypore_amd import synth
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    work = tempfile.mkdtemp(prefix="ppqc_cli_", dir=base)
+    try:
+        rng = np.random.default_rng(a.seed)
+        lens = synth.read_lengths(a.reads, a.mu, a.sigma, a.seed)
+        keep = int(np.searchsorted(np.cumsum(lens), a.cli_gbases * 1e9)) + 1
+        lens = lens[:keep]
+        R, nb = len(lens), int(lens.sum())
+        ch, _mux, t = synth.metadata(R, a.channels, a.time_bins, a.seed)
+        os.makedirs(os.path.join(work, "in"))
+        alphabet = np.frombuffer(b"ACGT", np.uint8)
+        n_files, text_bytes = 0, 0
+        for f0 in range(0, R, a.batch_reads):
+            f1 = min(R, f0 + a.batch_reads)
+            n = int(lens[f0:f1].sum())
+            seq = alphabet[rng.integers(0, 4, n, dtype=np.uint8)].tobytes()
+            qual = rng.integers(35, 75, n, dtype=np.uint8).tobytes()
+            parts, o = [], 0
+            for i in range(f0, f1):
+                L = int(lens[i])
+                parts.append(b"@read%08d runid=synthetic read=%d ch=%d start_time=%s\n%s\n+\n%s\n" % (
+                    i, i, int(ch[i]), time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(int(t[i]))).encode(),
+                    seq[o:o + L], qual[o:o + L]))
+                o += L
+            blob = b"".join(parts)
+            with open(os.path.join(work, "in", "f%05d.fastq" % n_files), "wb") as fh:
+                fh.write(blob)
+            n_files += 1
+            text_bytes += len(blob)
+        env = dict(os.environ)
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        cmd = [sys.executable, "-m", "pypore_amd.pypore", "seqstats", "-i", os.path.join(work, "in"), "-l", "bench", "-f",
+               "fastq", "-o", "out", "-v", "0"] + (["--gpus", str(a.gpus)] if a.gpus > 1 else [])
+        walls = []
+        for _ in range(max(1, a.steps if a.steps < 4 else 3)):
+            t0 = time.perf_counter()
+            rc = subprocess.call(cmd, cwd=work, env=env, stdout=subprocess.DEVNULL)
+            walls.append(time.perf_counter() - t0)
+            if rc != 0:
+                raise SystemExit("bench.py --cli: pypore seqstats failed (exit code %d)" % rc)
+        wall = min(walls)
+        ref = subprocess.run([sys.executable, "-m", "oracle.cli_leg", os.path.join(work, "in"), "--max-gbases", "0.5"],
+                             cwd=ROOT, capture_output=True, text=True)
+        ref_res = json.loads(ref.stdout.strip().splitlines()[-1]) if ref.returncode == 0 and ref.stdout.strip() else \
+            {"error": ref.stderr[-500:]}
+        out = {"metric": "Gbases/s of `pypore seqstats -f fastq`, wall clock of the whole command (not the headline metric)",
+               "value": round(nb / wall / 1e9, 3), "unit": "Gbases/s", "n_gpus": a.gpus, "wall_seconds": round(wall, 3),
+               "wall_seconds_all_runs": [round(w, 3) for w in walls], "file_GBps": round(text_bytes / wall / 1e9, 3),
+               "data": "synthetic", "dtype": "u8",
+               "config": {"workload": "%d reads, %.2f Gbases, %.2f GB of FASTQ text in %d files of %d records under %s; "
+                                      "summary + pore-activity HTML written" % (R, nb / 1e9, text_bytes / 1e9, n_files,
+                                                                                 a.batch_reads, base)},
+               "reference_shaped_cpu": ref_res}
+        if os.environ.get("PPQC_CLI_BREAKDOWN"):     # where the wall clock goes (tools/cli_breakdown.py), same files
+            subprocess.call([sys.executable, os.path.join(ROOT, "tools", "cli_breakdown.py"), os.path.join(work, "in")],
+                            cwd=work, env=env)
+        print(json.dumps(out), flush=True)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return 0
 
 
 def h2d_leg(a, torch, off, ch, mux, t, d_bases, d_quals, cfg):
