@@ -64,6 +64,34 @@ struct EvPair {
 
 }  // namespace
 
+// ---- the context's state: one phase, and what is known about the buffers ------------------------------------------------
+// `state` is the phase of the run-level aggregation: 0 reads only -> 1 extremes -> 2 tables -> 3 N50 (fetchable).  Every
+// call that adds reads, and ppqc_reset, puts it back to 0; a phase function checks the phase it needs (PPQC_E_STATE) and
+// sets its own.  The booleans beside it are facts about buffers and streams that decide WHERE work is enqueued, never
+// WHAT is computed; each has one place that makes it true and a short list that makes it false:
+//
+//   fact          true from                                   false from                                   read by
+//   res_clean     ppqc_create / ppqc_reset (results cleared   ppqc_finalize_extremes (the buffer is in      run_batch (index kernel at submit time),
+//                 on the main stream, ev_clean)                use from then on)                            finalize_extremes (no clear needed)
+//   pre_ok        ppqc_create / ppqc_reset                    a batch that could not leave its index-only   run_batch, finalize_extremes,
+//                                                              results early (time_mode 1, buffer in use),  ppqc_index_early / _stream_wait_index /
+//                                                              records / FASTQ text input, a reference      _n50_select_early
+//                                                              time that changes after batches
+//   pre_run       finalize_extremes when res_clean && pre_ok  ppqc_reset, the next finalize_extremes        finalize_n50 (host knows the largest key)
+//                 && reads (this finalize relies on them)
+//   lens_early    ppqc_create / ppqc_reset                    records / FASTQ text input (their lens32 is   finalize_extremes, finalize_n50,
+//                                                              written by the extremes kernel)              n50_select_hist (where the sort forks)
+//   n50_early     ppqc_n50_select_early round 2               any new batch, ppqc_reset                      finalize_tables (the finalize ends there)
+//   init_on_aux   finalize_extremes when the clear of the     finalize_extremes when an earlier phase may   n50_select_hist (round 0 may use aux)
+//                 results precedes everything on aux           still run (res_busy): clear stays in line
+//   res_busy      every finalize phase (mark_busy)            ppqc_sync (and all that call it)              finalize_extremes
+//   sum_fetched   ppqc_finalize's early result copy           finalize_extremes, fetch_tables                fetch_tables (no second copy; N50 from the
+//                                                                                                           mirror's spare word)
+//   m1_phase      ppqc_mode1_dist_phase (0, 1, 2 in order)    finalize_extremes (-1)                        finalize_tables (2: hours are done)
+//   fin_pending / end_split / fin_start / sort_start / sort_end: timing bookkeeping only (resolve_finalize_timings).
+//
+// tests/test_gpu_sequences.py drives random interleavings of every entry point against the oracle; any flag read before it
+// is defined on some path shows up there as a table that differs.
 struct ppqc_ctx {
     int device = 0, n_cu = 256;
     ppqc_config cfg{};
