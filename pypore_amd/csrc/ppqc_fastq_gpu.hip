@@ -6,13 +6,13 @@
 // ppqc_fastq_scan/pack accepts blank lines between records and reports the record number).
 //
 // The text is never compacted into separate base / quality streams.  Instead:
-//   1. nl_count + scan + nl_fill build the table of line starts (two streaming passes over the text);
+//   1. nl_index builds the table of line starts in one streaming pass over the text (chained scan, decoupled look-back);
 //   2. the per-read tile kernel runs in "line mode": bases = quals = text, offsets = line starts, so every LINE gets
 //      the raw sums of both classifiers (G/C/S and N counts, quality byte sum, fixed-point error sum);
 //   3. fastq_finalize (one thread per record) takes the base sums of line 2 and the quality sums of line 4, removes
 //      the contribution of the stripped line end from the quality sums, validates the record and writes the same
 //      per-read arrays finalize_reads writes.
-// Traffic: about 3 reads of the text (2.05 bytes per base each) and no write of the sequence bytes.
+// Traffic: two reads of the text (2.05 bytes per base each) and no write of the sequence bytes.
 #include "ppqc_internal.hpp"
 
 namespace ppqc {
@@ -74,115 +74,37 @@ __device__ __forceinline__ uint4 load_vec_clamped(const uint8_t* __restrict__ te
     return make_uint4(t[0], t[1], t[2], t[3]);
 }
 
-// one wave per chunk of kNlChunk bytes
-__global__ __launch_bounds__(256) void nl_count_kernel(const uint8_t* __restrict__ text, uint64_t n,
-                                                       uint32_t* __restrict__ counts, uint64_t n_chunks) {
+// ---- the table of line starts in ONE pass over the text -----------------------------------------------------------------
+// A chained scan: one wave per chunk of kNlChunk bytes counts its newlines from registers, publishes the count, learns
+// the number of newlines in front of its chunk from what the chunks before it have published, and then places its own
+// line starts -- the text is read once, where counting, scanning and filling took two passes (0.60 + 0.62 ms for 3.97 GB)
+// and four launches in between.  A plain decoupled look-back is no good here: some 4000 waves are resident at once, all
+// of them publish their counts at about the same time and every one would walk back over all the others, 64 at a time
+// (measured: 58 ms).  So the walk has two levels.  Chunks form groups of 64; the wave of a group's last chunk publishes
+// the group's total as soon as its 63 predecessors have published their counts, and the group's inclusive prefix once it
+// knows what lies in front of the group.  A wave then needs two steps: the counts of the chunks of its own group in front
+// of it (one load per lane), and a look-back over GROUP words -- the 4000 resident waves are 64 groups, one load per lane.
+//   word = flag << 62 | value.  chunk words: 1 = the chunk's count.  group words: 1 = the group's total, 2 = the inclusive
+//   prefix up to and including the group.  One 64-bit word, so a reader never sees a flag without its value -- and since
+//   nothing else is handed over, the accesses are RELAXED device-scope atomics: a release / acquire pair at device scope
+//   writes back and invalidates the XCD's whole L2 on this part (measured: 0.75 ms for an 80 MB text).
+// Chunks are handed out by a ticket counter (one ticket per block of 16 waves), in the order blocks START: a wave only ever waits for chunks whose waves are
+// already running, and those wait for nothing behind them -- every wave's walk ends.
+// status = [chunk words: n_chunks | ticket | newlines of the whole text | group words: ceil(n_chunks / 64)]
+constexpr uint64_t kStatusCount = 1ull << 62, kStatusPrefix = 2ull << 62, kStatusValue = (1ull << 62) - 1;
+
+constexpr int kNlWaves = 16;   // waves per block: one ticket per block (a ticket per wave: 484 000 atomics on one word, 6 ms)
+
+__global__ __launch_bounds__(64 * kNlWaves) void nl_index_kernel(const uint8_t* __restrict__ text, uint64_t n, uint64_t* status,
+                                                       uint64_t n_chunks, uint64_t* __restrict__ line_off,
+                                                       uint64_t line_cap, uint64_t* __restrict__ errors) {
     const int lane = threadIdx.x & 63;
-    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ uint64_t s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd((unsigned long long*)&status[n_chunks], 1ull);
+    __syncthreads();   // the only block-level barrier: nothing below may wait for a wave of this block to reach one
+    const uint64_t chunk = uniform_u64(s_ticket * kNlWaves + (threadIdx.x >> 6));
     if (chunk >= n_chunks) return;
-    uint32_t c = 0;
-#pragma unroll
-    for (int it = 0; it < (int)(kNlChunk / kSpan); ++it) {
-        const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
-        if (pos < n) {
-            const uint4 v = load_vec_clamped(text, pos, n);
-            const uint64_t rem = n - pos;
-            c += __popc(vec_nl_bits(v, rem < 16 ? (int)rem : 16));
-        }
-    }
-    c = (uint32_t)wave_sum_u64(c);
-    if (lane == 0) counts[chunk] = c;
-}
-
-constexpr int kScanBlock = 2048;   // entries per block of the two-level scan
-uint64_t nl_scan_block_words(uint64_t n_chunks) { return (n_chunks + kScanBlock - 1) / kScanBlock + 2; }
-
-__global__ __launch_bounds__(256) void nl_blocksum_kernel(const uint32_t* __restrict__ counts, uint64_t n,
-                                                          uint64_t* __restrict__ bsum) {
-    __shared__ unsigned long long acc;
-    if (threadIdx.x == 0) acc = 0;
-    __syncthreads();
-    uint64_t t = 0;
-    for (int k = 0; k < kScanBlock / 256; ++k) {
-        const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)k * 256 + threadIdx.x;
-        if (i < n) t += counts[i];
-    }
-    t = wave_sum_u64(t);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&acc, (unsigned long long)t);
-    __syncthreads();
-    if (threadIdx.x == 0) bsum[blockIdx.x] = acc;
-}
-
-// single block: exclusive scan of the block sums in place; grand total -> *total
-__global__ __launch_bounds__(256) void nl_scan_top_kernel(uint64_t* __restrict__ bsum, uint64_t nblocks,
-                                                          uint64_t* __restrict__ total) {
-    __shared__ uint64_t part[256];
-    const uint32_t t = threadIdx.x;
-    const uint64_t seg = (nblocks + 255) / 256;
-    const uint64_t b = t * seg, e = b + seg < nblocks ? b + seg : nblocks;
-    uint64_t s = 0;
-    for (uint64_t i = b; i < e; ++i) s += bsum[i];
-    part[t] = s;
-    __syncthreads();
-    if (t == 0) {
-        uint64_t run = 0;
-        for (int i = 0; i < 256; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; }
-        *total = run;
-    }
-    __syncthreads();
-    uint64_t run = part[t];
-    for (uint64_t i = b; i < e; ++i) { const uint64_t v = bsum[i]; bsum[i] = run; run += v; }
-}
-
-// per block of kScanBlock entries: thread owns 8 consecutive entries
-__global__ __launch_bounds__(256) void nl_scan_apply_kernel(const uint32_t* __restrict__ counts, uint64_t n,
-                                                            const uint64_t* __restrict__ bsum,
-                                                            uint64_t* __restrict__ prefix) {
-    __shared__ uint64_t part[256];
-    const uint32_t t = threadIdx.x;
-    const uint64_t b0 = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)t * 8;
-    uint32_t v[8];
-    uint64_t loc = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { v[k] = b0 + k < n ? counts[b0 + k] : 0; loc += v[k]; }
-    part[t] = loc;
-    __syncthreads();
-    if (t == 0) {
-        uint64_t run = bsum[blockIdx.x];
-        for (int i = 0; i < 256; ++i) { const uint64_t x = part[i]; part[i] = run; run += x; }
-    }
-    __syncthreads();
-    uint64_t run = part[t];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        if (b0 + k < n) prefix[b0 + k] = run;
-        run += v[k];
-    }
-}
-
-hipError_t launch_nl_count_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, hipStream_t s) {
-    const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
-    if (n_chunks == 0) return hipMemsetAsync(fs.prefix, 0, 8, s);
-    hipLaunchKernelGGL(nl_count_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, text, n, fs.counts, n_chunks);
-    const uint64_t nblocks = (n_chunks + kScanBlock - 1) / kScanBlock;
-    hipLaunchKernelGGL(nl_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, fs.counts, n_chunks, fs.block_sums);
-    hipLaunchKernelGGL(nl_scan_top_kernel, dim3(1), dim3(256), 0, s, fs.block_sums, nblocks, fs.prefix + n_chunks);
-    hipLaunchKernelGGL(nl_scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, fs.counts, n_chunks,
-                       fs.block_sums, fs.prefix);
-    return hipGetLastError();
-}
-
-// one wave per chunk again: the k-th newline of the text (0-based) at byte p sets line_off[k + 1] = p + 1
-__global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict__ text, uint64_t n,
-                                                      const uint64_t* __restrict__ prefix, uint64_t n_chunks,
-                                                      uint64_t* __restrict__ line_off, uint64_t n_lines,
-                                                      uint64_t* __restrict__ errors) {
-    const int lane = threadIdx.x & 63;
-    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { line_off[0] = 0; line_off[n_lines] = n; }
-    if (chunk >= n_chunks) return;
-    uint64_t base = uniform_u64(prefix[chunk]);
-    uint32_t nbad = 0;
+    if (chunk == 0 && lane == 0) line_off[0] = 0;
     constexpr int kIt = (int)(kNlChunk / kSpan);
     uint4 vv[kIt];
 #pragma unroll
@@ -190,27 +112,75 @@ __global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict_
         const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
         vv[it] = load_vec_clamped(text, pos < n ? pos : 0, n);
     }
+    uint32_t nlb[kIt], cnt = 0;
 #pragma unroll
     for (int it = 0; it < kIt; ++it) {
         const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
-        uint32_t bits = 0, bad = 0;
+        const uint4& v = vv[it];
+        nlb[it] = 0;
         // nearly every vector holds only '!'..'~' bytes: one cheap test, the exact masks only where it fires
+        if (pos < n && (odd_byte_mask(v.x) | odd_byte_mask(v.y) | odd_byte_mask(v.z) | odd_byte_mask(v.w))) {
+            const uint64_t rem = n - pos;
+            nlb[it] = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
+        }
+        cnt += __popc(nlb[it]);
+    }
+    const uint64_t mine = wave_sum_u32(cnt);   // <= 8192
+    uint64_t* __restrict__ gs = status + n_chunks + 2;
+    const uint64_t g = chunk >> 6;
+    const int m = (int)(chunk & 63);
+    if (lane == 0) __hip_atomic_store(&status[chunk], kStatusCount | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t within = 0;   // newlines of the chunks of this group in front of this one
+    if (m) {
+        for (;;) {
+            uint64_t st = kStatusCount;
+            if (lane < m) st = __hip_atomic_load(&status[(g << 6) + (uint64_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot((st >> 62) == 0)) { __builtin_amdgcn_s_sleep(1); continue; }
+            within = wave_sum_u64(lane < m ? (st & kStatusValue) : 0);
+            break;
+        }
+    }
+    const bool closes = m == 63;   // this wave speaks for its group
+    if (closes && lane == 0)
+        __hip_atomic_store(&gs[g], kStatusCount | (within + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t front = 0;    // newlines in front of this group
+    if (g) {
+        int64_t pos = (int64_t)g - 1;
+        for (;;) {   // 64 groups at a time, nearest in lane 0
+            const int64_t idx = pos - lane;
+            uint64_t st = kStatusPrefix;   // in front of the text: prefix 0
+            if (idx >= 0) st = __hip_atomic_load(&gs[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t isP = __ballot((st >> 62) == 2), isX = __ballot((st >> 62) == 0);
+            const int firstP = isP ? __builtin_ctzll(isP) : 64;
+            const uint64_t upto = firstP >= 63 ? ~0ull : ((2ull << firstP) - 1ull);
+            if (isX & upto) { __builtin_amdgcn_s_sleep(1); continue; }   // a group in between has not closed yet
+            front += wave_sum_u64(lane <= firstP ? (st & kStatusValue) : 0);
+            if (firstP != 64) break;
+            pos -= 64;
+        }
+    }
+    const uint64_t excl = front + within;
+    if (closes && lane == 0)
+        __hip_atomic_store(&gs[g], kStatusPrefix | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (chunk == n_chunks - 1 && lane == 0) status[n_chunks + 1] = excl + mine;
+    // place the line starts: the k-th newline of the text (0-based) at byte p sets line_off[k + 1] = p + 1
+    uint64_t base = excl;
+    uint32_t nbad = 0;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
+        uint32_t bits = nlb[it], bad = 0;
         const uint4& v = vv[it];
         if (pos < n && (odd_byte_mask(v.x) | odd_byte_mask(v.y) | odd_byte_mask(v.z) | odd_byte_mask(v.w))) {
             const uint64_t rem = n - pos;
-            bits = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
             bad = vec_badq_bits(v, rem < 16 ? (int)rem : 16);
         }
-        const uint32_t cnt = __popc(bits);
-        uint32_t inc = cnt;   // inclusive wave prefix of the lane counts
+        const uint32_t c = __popc(bits);
+        uint32_t inc = c;   // inclusive wave prefix of the lane counts
         if (__ballot(bits != 0) != 0) {   // most 1 KiB spans lie inside one line: no newline, nothing to scan
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t u = __shfl_up(inc, o);
-                if (lane >= o) inc += u;
-            }
+            inc = wave_scan_incl_u32(c);
         }
-        uint64_t k = base + (inc - cnt);   // number of the line the vector starts in
+        uint64_t k = base + (inc - c);   // number of the line the vector starts in
         // quality lines are the lines 3 (mod 4): count their invalid bytes (what SeqIO rejects, lib/seq_routines.py:50)
         if (bad) {
             if (!bits) nbad += (k & 3) == 3 ? __popc(bad) : 0;
@@ -223,21 +193,26 @@ __global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict_
         while (bits) {
             const int b = __ffs((int)bits) - 1;
             bits &= bits - 1;
-            if (k + 1 < n_lines) line_off[k + 1] = pos + (uint64_t)b + 1;   // a final newline at n - 1 is line_off[n_lines] = n
+            if (k + 1 <= line_cap) line_off[k + 1] = pos + (uint64_t)b + 1;   // beyond the table's capacity: counted only
             ++k;
         }
         base += (uint32_t)__shfl((int)inc, 63);
     }
-    nbad = (uint32_t)wave_sum_u64(nbad);
+    nbad = wave_sum_u32(nbad);
     if (lane == 0 && nbad) atomicAdd((unsigned long long*)&errors[3], (unsigned long long)nbad);
 }
 
-hipError_t launch_nl_fill(const uint8_t* text, uint64_t n, uint64_t n_lines, const FastqScratch& fs, uint64_t* errors,
-                          hipStream_t s) {
+uint64_t nl_status_words(uint64_t n_chunks) { return n_chunks + 2 + (n_chunks + 63) / 64; }
+
+// status: nl_status_words(n_chunks) u64.  Leaves line_off[0 .. min(lines, line_cap)] and the number of newlines in
+// status[n_chunks + 1]; the caller sets line_off[n_lines] = n for a text without a final newline.
+hipError_t launch_nl_index(const uint8_t* text, uint64_t n, uint64_t* status, uint64_t* line_off, uint64_t line_cap,
+                           uint64_t* errors, hipStream_t s) {
     const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
-    const uint64_t blocks = n_chunks ? (n_chunks + 3) / 4 : 1;
-    hipLaunchKernelGGL(nl_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, text, n, fs.prefix, n_chunks, fs.line_off,
-                       n_lines, errors);
+    hipError_t e = hipMemsetAsync(status, 0, nl_status_words(n_chunks) * 8, s);
+    if (e != hipSuccess || n_chunks == 0) return e;
+    hipLaunchKernelGGL(nl_index_kernel, dim3((unsigned)((n_chunks + kNlWaves - 1) / kNlWaves)), dim3(64 * kNlWaves), 0, s, text, n, status, n_chunks,
+                       line_off, line_cap, errors);
     return hipGetLastError();
 }
 

@@ -151,20 +151,16 @@ hipError_t launch_select_pick(uint64_t* sel, const uint64_t* total, uint64_t* st
                               bool first, uint64_t* out, hipStream_t s);   // total == nullptr: from the first round's histogram
 
 // ---- FASTQ text on the GPU (ppqc_fastq_gpu.hip) --------------------------------------------------------------------
-constexpr uint32_t kNlChunk = 4096;   // bytes of text per newline-count entry (one wave, four 1 KiB spans)
+constexpr uint32_t kNlChunk = 8192;   // bytes of text per wave of the line-index kernel (eight 1 KiB spans in registers)
 struct FastqScratch {
-    uint32_t* counts;       // newlines per chunk
-    uint64_t* prefix;       // exclusive prefix of counts; prefix[n_chunks] = total
-    uint64_t* block_sums;   // scan scratch
+    uint64_t* status;       // chained-scan words of the line-index kernel (nl_status_words)
     uint64_t* line_off;     // n_lines + 1 line starts (the CSR offsets of the line-mode tile kernel)
 };
-uint64_t nl_scan_block_words(uint64_t n_chunks);
-// counts newlines per chunk and scans them; the total lands in fs.prefix[n_chunks]
-hipError_t launch_nl_count_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, hipStream_t s);
-// line_off[0] = 0, line_off[k + 1] = position after the k-th newline, line_off[n_lines] = n
-// also counts, in errors[3], the bytes of quality lines outside '!'..'~' (white space excepted)
-hipError_t launch_nl_fill(const uint8_t* text, uint64_t n, uint64_t n_lines, const FastqScratch& fs, uint64_t* errors,
-                          hipStream_t s);
+uint64_t nl_status_words(uint64_t n_chunks);
+// line_off[0] = 0, line_off[k + 1] = position after the k-th newline for k + 1 <= line_cap; the number of newlines lands
+// in status[n_chunks + 1].  Also counts, in errors[3], the bytes of quality lines outside '!'..'~' (white space excepted).
+hipError_t launch_nl_index(const uint8_t* text, uint64_t n, uint64_t* status, uint64_t* line_off, uint64_t line_cap,
+                           uint64_t* errors, hipStream_t s);
 // one thread per record: validates the four lines, strips line ends, merges the line sums into the per-read arrays,
 // parses ch= and start_time= out of the header.  errors[1] counts malformed records.
 hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
@@ -213,6 +209,17 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     v = dpp_add_u32<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
     v = dpp_add_u32<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// Inclusive scan of a u32 over the 64 lanes (every partial sum must fit 32 bits): row_shr steps inside each row of 16,
+// then row_bcast:15 / row_bcast:31 carry the row totals upwards.
+__device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v) {
+    v = dpp_add_u32<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add_u32<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add_u32<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add_u32<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_add_u32<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add_u32<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
 }
 // Raw sums of the segment [a, e) of the byte streams (e > a) whose record index is g: complete in rec_* when it lies
 // in one tile, else the tail partial of its first tile plus the head partials of the following ones, in tile order.

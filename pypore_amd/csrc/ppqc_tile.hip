@@ -619,15 +619,7 @@ struct Carry {   // wave-uniform: sums of the open read that are not in the per-
     uint64_t hi, lo;   // S = hi * 2^32 + lo
 };
 
-__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {   // inclusive; every partial sum must fit 32 bits
-    v = dpp_add_u32<0x111, 0xf>(v);   // row_shr:1
-    v = dpp_add_u32<0x112, 0xf>(v);   // row_shr:2
-    v = dpp_add_u32<0x114, 0xf>(v);   // row_shr:4
-    v = dpp_add_u32<0x118, 0xf>(v);   // row_shr:8  -> scan inside each row of 16
-    v = dpp_add_u32<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v = dpp_add_u32<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) { return wave_scan_incl_u32(v); }   // ppqc_internal.hpp
 
 // Span-level sums (one 16-byte vector per stream and lane, at most 64 lanes added up) in four u32 pieces:
 //   c1 = gcs | n << 16          (each <= 1024)

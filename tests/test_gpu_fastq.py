@@ -152,3 +152,32 @@ def test_invalid_quality_bytes_are_counted_like_the_host_packer(qc_mod):
         ctx.finalize()                 # reported, not fatal (the bytes are clamped as in ppqc_submit)
         ctx.reset()
         assert ctx.input_errors()["bad_quality_bytes"] == 0
+
+
+def test_dense_text_grows_the_line_table_and_counts_once(qc_mod, c_oracle):
+    """The line table is sized before the lines are counted (64 bytes per line to begin with).  Reads of a few bases
+    give four lines in about 40 bytes: the single-pass index kernel then counts more lines than the table holds, the
+    table grows and the pass runs again -- with the same records, tables and invalid-quality-byte count as the host
+    packer, not twice the count.  A second, sparser text on the same context then fits at once."""
+    from pypore_amd import fastq_io
+    rng = np.random.default_rng(12)
+    recs = []
+    for i in range(30_000):
+        L = int(rng.integers(0, 6))
+        q = rng.integers(33, 127, L, dtype=np.uint8)
+        if L and i % 50 == 0:
+            q[0] = 200                                      # invalid as a quality
+        recs.append(b"@r%d ch=%d\n" % (i, 1 + i % 512) + bytes(rng.choice(ALPH, L)) + b"\n+\n" + bytes(q) + b"\n")
+    text = b"".join(recs)
+    assert len(text) / (4 * len(recs)) < 20
+    p, want, _ = _host_path(qc_mod, c_oracle, text)
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        assert ctx.submit_fastq(text) == len(recs)
+        _check(ctx.read_stats(), want)
+        assert ctx.input_errors()["bad_quality_bytes"] == p["n_bad_qual"] > 100
+        ctx.reset()
+        sparse = _text(13, 500)
+        p2, want2, wt2 = _host_path(qc_mod, c_oracle, sparse)
+        assert ctx.submit_fastq(sparse) == 500
+        _check(ctx.read_stats(), want2)
+        assert_tables_equal(ctx.finalize(), wt2)
