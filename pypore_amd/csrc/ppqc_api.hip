@@ -140,8 +140,6 @@ struct ppqc_ctx {
     FastqScratch fq{};
     ReadArrays lra{};           // rec_* only: raw sums per text line
     uint64_t cap_chunks = 0, cap_lines = 0;
-    uint64_t fq_bytes_per_line = 0;   // the densest text seen so far (sizes the line table before the lines are counted)
-    uint64_t* fq_bad_save = nullptr;  // one device word: errors[3] as it was in front of the line-index pass
 
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> ev_pool;
@@ -155,6 +153,7 @@ struct ppqc_ctx {
     bool pre_run = false;   // ... and the finalize in progress relies on it (set by ppqc_finalize_extremes)
     bool n50_early = false; // ppqc_n50_select_early has left the N50 of the run's reads (no batch since)
     hipEvent_t ev_pre = nullptr;   // behind the newest of those kernels (auxiliary stream)
+    hipEvent_t ev_fq0 = nullptr, ev_fq1 = nullptr;   // FASTQ text: line table ready / headers parsed (auxiliary stream)
     hipEvent_t ev_clean = nullptr; // behind the clear of the result buffer (ppqc_reset / ppqc_create, main stream)
     uint64_t* maxlen_host = nullptr;   // a few pinned scratch words (line count of the GPU tokenizer)
     uint64_t* m1 = nullptr;            // time_mode 1 across ranks: [first | ties | days] (ppqc_mode1_dist_view)
@@ -363,12 +362,13 @@ static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_max, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_clean, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fq0, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fq1, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->ev_join));
     HIPCHK(hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->ev_reads));
     HIPCHK(hipHostMalloc((void**)&c->maxlen_host, 64, hipHostMallocDefault));
-    HIPCHK(hipMalloc((void**)&c->fq_bad_save, 64));
 
     // error-probability LUT: e[b] = round(2^52 * 10^(-q/10)), q = clamp(b - 33, 0, 93)
     uint64_t lut[256];
@@ -453,14 +453,16 @@ int ppqc_destroy(ppqc_ctx* c) {
     ReadArrays& r = c->ra;
     void* ptrs[] = {r.rec_cnt, r.rec_hi, r.rec_lo, r.len, r.gc, r.nn, r.qsum, r.mean_q, r.err_hi, r.err_lo, r.flags,
                     r.channel, r.mux, r.time, r.hour, r.lens32, c->head, c->tail, c->res_buf, c->sk32, c->sk32_tmp, c->counts, c->vals, c->vals_tmp, c->sk64,
-                    c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev, c->dense.base, c->fq.status, c->fq_bad_save,
-                    c->fq.line_off, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo, c->m1};
+                    c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev, c->dense.base, c->fq.counts, c->fq.n_entries, c->fq.entries, c->fq.prefix,
+                    c->fq.block_sums, c->fq.line_off, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo, c->m1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->maxlen_host) (void)hipHostFree(c->maxlen_host);
     if (c->ev_max) (void)hipEventDestroy(c->ev_max);
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     if (c->ev_clean) (void)hipEventDestroy(c->ev_clean);
+    if (c->ev_fq0) (void)hipEventDestroy(c->ev_fq0);
+    if (c->ev_fq1) (void)hipEventDestroy(c->ev_fq1);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_reads) (void)hipEventDestroy(c->ev_reads);
@@ -645,51 +647,44 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
     if (n_chunks > c->cap_chunks) {
         const uint64_t cap = n_chunks + n_chunks / 4 + 64;
-        CHK(grow(&c->fq.status, 0, nl_status_words(cap), s));
+        CHK(grow(&c->fq.counts, 0, cap, s)); CHK(grow(&c->fq.n_entries, 0, cap, s));
+        CHK(grow(&c->fq.entries, 0, cap * kNlEntriesPerChunk, s));
+        CHK(grow(&c->fq.prefix, 0, cap + 2, s));
+        CHK(grow(&c->fq.block_sums, 0, nl_scan_block_words(cap), s));
         c->cap_chunks = cap;
     }
-    // The line table has to exist before the lines are counted: it is sized by the densest text seen so far (64 bytes
-    // per line to begin with: reads of 100 bases and more).  The kernel counts every line but places only those the
-    // table holds; a denser text grows the table and runs the pass again, once.
-    uint64_t* h = c->maxlen_host;   // pinned scratch words [1] = newlines, [2] = last byte, [3] = n
-    uint64_t n_lines = 0;
-    for (int attempt = 0;; ++attempt) {
-        uint64_t want = n / (c->fq_bytes_per_line ? c->fq_bytes_per_line : 64) + 1024;
-        if (want > c->cap_lines) {
-            const uint64_t cap = want + want / 4;
-            CHK(grow(&c->fq.line_off, 0, cap + 1, s));
-            CHK(grow(&c->lra.rec_cnt, 0, cap, s)); CHK(grow(&c->lra.rec_hi, 0, cap, s)); CHK(grow(&c->lra.rec_lo, 0, cap, s));
-            c->cap_lines = cap;
-        }
-        uint64_t* errw = c->res_buf + c->res_words;
-        // the pass adds the text's invalid quality bytes to errors[3]: a second pass starts from the saved count
-        if (attempt == 0) HIPCHK(hipMemcpyAsync(c->fq_bad_save, errw + 3, 8, hipMemcpyDeviceToDevice, s));
-        else HIPCHK(hipMemcpyAsync(errw + 3, c->fq_bad_save, 8, hipMemcpyDeviceToDevice, s));
-        HIPCHK(launch_nl_index(text, n, c->fq.status, c->fq.line_off, c->cap_lines, errw, s));
-        h[2] = 0;
-        HIPCHK(hipMemcpyAsync(&h[1], c->fq.status + n_chunks + 1, 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(&h[2], text + n - 1, 1, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        n_lines = h[1] + (((uint8_t)h[2]) != '\n' ? 1 : 0);
-        if (n_lines <= c->cap_lines) break;
-        if (attempt) return fail(PPQC_E_HIP, "line table too small after growing it");
-        c->fq_bytes_per_line = n / n_lines ? n / n_lines : 1;   // denser than anything before: size for it and go again
-    }
+    HIPCHK(launch_nl_scan(text, n, c->fq, s));
+    uint64_t* h = c->maxlen_host;   // pinned scratch words [1] = newlines, [2] = chunks with too many odd vectors, [3] = last byte
+    h[3] = 0;
+    HIPCHK(hipMemcpyAsync(&h[1], c->fq.prefix + n_chunks, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&h[3], text + n - 1, 1, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const uint64_t n_lines = h[1] + (((uint8_t)h[3]) != '\n' ? 1 : 0);
+    const bool sparse = h[2] == 0;
     if (n_lines % 4 != 0)
         return fail(PPQC_E_INVALID, "FASTQ text has " + std::to_string(n_lines) + " lines, not a multiple of 4 (blank "
                                         "lines or multi-line records: use ppqc_fastq_scan / ppqc_fastq_pack)");
     const uint64_t R = n_lines / 4;
     if (R >= (1ull << 30)) return fail(PPQC_E_RANGE, "more than 2^30-1 records in one text");
-    if (((uint8_t)h[2]) != '\n') {   // no final newline: the last line ends with the text
-        h[3] = n;
-        HIPCHK(hipMemcpyAsync(c->fq.line_off + n_lines, &h[3], 8, hipMemcpyHostToDevice, s));
+    if (n_lines > c->cap_lines) {
+        const uint64_t cap = n_lines + n_lines / 4 + 64;
+        CHK(grow(&c->fq.line_off, 0, cap + 1, s));
+        CHK(grow(&c->lra.rec_cnt, 0, cap, s)); CHK(grow(&c->lra.rec_hi, 0, cap, s)); CHK(grow(&c->lra.rec_lo, 0, cap, s));
+        c->cap_lines = cap;
     }
+    HIPCHK(launch_nl_place(text, n, n_lines, sparse, c->fq, c->res_buf + c->res_words, s));
     CHK(ensure_reads(c, c->n_reads + R));
     const uint32_t shift = kDefaultTileShift;
     CHK(ensure_tiles(c, (n + (1ull << shift) - 1) >> shift));
+    // the headers are parsed on the auxiliary stream, beside the tile kernel: both need the line table only
+    HIPCHK(hipEventRecord(c->ev_fq0, s));
+    HIPCHK(hipStreamWaitEvent(c->aux, c->ev_fq0, 0));
+    HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, c->aux));
+    HIPCHK(hipEventRecord(c->ev_fq1, c->aux));
     // line mode: both classifiers run over the same text, every line is a segment
     BatchView v{text, text, c->fq.line_off, n_lines, n, nullptr, shift, nullptr, nullptr, nullptr};
     HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->dense, c->n_cu, s, true));
+    HIPCHK(hipStreamWaitEvent(s, c->ev_fq1, 0));
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
                                  c->lut_dev, c->tp.thr_fail, c->tp.fail_q, mux, c->res_buf + c->res_words, s));
     c->n_reads += R;

@@ -6,13 +6,14 @@
 // ppqc_fastq_scan/pack accepts blank lines between records and reports the record number).
 //
 // The text is never compacted into separate base / quality streams.  Instead:
-//   1. nl_index builds the table of line starts in one streaming pass over the text (chained scan, decoupled look-back);
+//   1. the table of line starts: one streaming pass over the text that counts newlines and notes the few vectors that hold
+//      one, a scan, and a placement from those notes (a second pass over the text only when lines are short);
 //   2. the per-read tile kernel runs in "line mode": bases = quals = text, offsets = line starts, so every LINE gets
 //      the raw sums of both classifiers (G/C/S and N counts, quality byte sum, fixed-point error sum);
 //   3. fastq_finalize (one thread per record) takes the base sums of line 2 and the quality sums of line 4, removes
 //      the contribution of the stripped line end from the quality sums, validates the record and writes the same
 //      per-read arrays finalize_reads writes.
-// Traffic: two reads of the text (2.05 bytes per base each) and no write of the sequence bytes.
+// Traffic: two reads of the text (2.05 bytes per base each; three when lines are short) and no write of the sequence bytes.
 #include "ppqc_internal.hpp"
 
 namespace ppqc {
@@ -74,37 +75,28 @@ __device__ __forceinline__ uint4 load_vec_clamped(const uint8_t* __restrict__ te
     return make_uint4(t[0], t[1], t[2], t[3]);
 }
 
-// ---- the table of line starts in ONE pass over the text -----------------------------------------------------------------
-// A chained scan: one wave per chunk of kNlChunk bytes counts its newlines from registers, publishes the count, learns
-// the number of newlines in front of its chunk from what the chunks before it have published, and then places its own
-// line starts -- the text is read once, where counting, scanning and filling took two passes (0.60 + 0.62 ms for 3.97 GB)
-// and four launches in between.  A plain decoupled look-back is no good here: some 4000 waves are resident at once, all
-// of them publish their counts at about the same time and every one would walk back over all the others, 64 at a time
-// (measured: 58 ms).  So the walk has two levels.  Chunks form groups of 64; the wave of a group's last chunk publishes
-// the group's total as soon as its 63 predecessors have published their counts, and the group's inclusive prefix once it
-// knows what lies in front of the group.  A wave then needs two steps: the counts of the chunks of its own group in front
-// of it (one load per lane), and a look-back over GROUP words -- the 4000 resident waves are 64 groups, one load per lane.
-//   word = flag << 62 | value.  chunk words: 1 = the chunk's count.  group words: 1 = the group's total, 2 = the inclusive
-//   prefix up to and including the group.  One 64-bit word, so a reader never sees a flag without its value -- and since
-//   nothing else is handed over, the accesses are RELAXED device-scope atomics: a release / acquire pair at device scope
-//   writes back and invalidates the XCD's whole L2 on this part (measured: 0.75 ms for an 80 MB text).
-// Chunks are handed out by a ticket counter (one ticket per block of 16 waves), in the order blocks START: a wave only ever waits for chunks whose waves are
-// already running, and those wait for nothing behind them -- every wave's walk ends.
-// status = [chunk words: n_chunks | ticket | newlines of the whole text | group words: ceil(n_chunks / 64)]
-constexpr uint64_t kStatusCount = 1ull << 62, kStatusPrefix = 2ull << 62, kStatusValue = (1ull << 62) - 1;
+// ---- the table of line starts ------------------------------------------------------------------------------------------
+// Pass 1 (nl_scan_kernel, one wave per chunk of kNlChunk bytes, the only full read of the text when lines are long):
+// counts the chunk's newlines and writes down its ODD VECTORS -- the 16-byte vectors that hold a newline or a byte that
+// is invalid as a quality -- as (vector, newline bits, invalid bits) entries, at most kNlEntries per chunk.  Reads of
+// 500 bases and more give a chunk a handful (a line end every 1 KiB at a mean of 500: 8 of 512 vectors).  A scan of the
+// counts numbers the lines; the host, which has to wait for the count anyway to size the tables, also learns whether any
+// chunk had more odd vectors than its list holds.  If none: nl_place_kernel, half a wave per chunk, places the line
+// starts from the entries (a few MB) without touching the text again.  Else (short reads: most vectors hold a line end)
+// nl_fill_kernel reads the text a second time, as it always did.
+// No wave waits for another one.  (Tried: one pass by a chained scan with decoupled look-back over two levels; correct, but
+// some 4000 resident waves polling status words across the XCDs made it 1.94 ms for 3.97 GB, against 0.60 + 0.62 ms for
+// the two passes.)
+constexpr int kNlEntries = (int)kNlEntriesPerChunk;
 
-constexpr int kNlWaves = 16;   // waves per block: one ticket per block (a ticket per wave: 484 000 atomics on one word, 6 ms)
-
-__global__ __launch_bounds__(64 * kNlWaves) void nl_index_kernel(const uint8_t* __restrict__ text, uint64_t n, uint64_t* status,
-                                                       uint64_t n_chunks, uint64_t* __restrict__ line_off,
-                                                       uint64_t line_cap, uint64_t* __restrict__ errors) {
+// entry = vector index in the chunk (bits 32..41) | newline bits (0..15) | invalid-quality bits (16..31)
+__global__ __launch_bounds__(256) void nl_scan_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                      uint32_t* __restrict__ counts, uint32_t* __restrict__ n_entries,
+                                                      uint64_t* __restrict__ entries, uint64_t n_chunks,
+                                                      uint64_t* __restrict__ overflow) {
     const int lane = threadIdx.x & 63;
-    __shared__ uint64_t s_ticket;
-    if (threadIdx.x == 0) s_ticket = atomicAdd((unsigned long long*)&status[n_chunks], 1ull);
-    __syncthreads();   // the only block-level barrier: nothing below may wait for a wave of this block to reach one
-    const uint64_t chunk = uniform_u64(s_ticket * kNlWaves + (threadIdx.x >> 6));
+    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (chunk >= n_chunks) return;
-    if (chunk == 0 && lane == 0) line_off[0] = 0;
     constexpr int kIt = (int)(kNlChunk / kSpan);
     uint4 vv[kIt];
 #pragma unroll
@@ -112,75 +104,176 @@ __global__ __launch_bounds__(64 * kNlWaves) void nl_index_kernel(const uint8_t* 
         const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
         vv[it] = load_vec_clamped(text, pos < n ? pos : 0, n);
     }
-    uint32_t nlb[kIt], cnt = 0;
+    uint32_t cnt = 0, ne = 0;   // ne: wave-uniform
 #pragma unroll
     for (int it = 0; it < kIt; ++it) {
         const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
         const uint4& v = vv[it];
-        nlb[it] = 0;
+        uint32_t bits = 0, bad = 0;
         // nearly every vector holds only '!'..'~' bytes: one cheap test, the exact masks only where it fires
         if (pos < n && (odd_byte_mask(v.x) | odd_byte_mask(v.y) | odd_byte_mask(v.z) | odd_byte_mask(v.w))) {
             const uint64_t rem = n - pos;
-            nlb[it] = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
+            bits = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
+            bad = vec_badq_bits(v, rem < 16 ? (int)rem : 16);
         }
-        cnt += __popc(nlb[it]);
-    }
-    const uint64_t mine = wave_sum_u32(cnt);   // <= 8192
-    uint64_t* __restrict__ gs = status + n_chunks + 2;
-    const uint64_t g = chunk >> 6;
-    const int m = (int)(chunk & 63);
-    if (lane == 0) __hip_atomic_store(&status[chunk], kStatusCount | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint64_t within = 0;   // newlines of the chunks of this group in front of this one
-    if (m) {
-        for (;;) {
-            uint64_t st = kStatusCount;
-            if (lane < m) st = __hip_atomic_load(&status[(g << 6) + (uint64_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__ballot((st >> 62) == 0)) { __builtin_amdgcn_s_sleep(1); continue; }
-            within = wave_sum_u64(lane < m ? (st & kStatusValue) : 0);
-            break;
+        cnt += __popc(bits);
+        const uint64_t odd = __ballot((bits | bad) != 0);
+        if (odd) {
+            const uint32_t at = ne + __builtin_amdgcn_mbcnt_hi((uint32_t)(odd >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)odd, 0u));
+            if ((bits | bad) != 0 && at < (uint32_t)kNlEntries)
+                entries[chunk * kNlEntries + at] = ((uint64_t)(it * 64 + lane) << 32) | ((uint64_t)bad << 16) | bits;
+            ne += (uint32_t)__popcll(odd);
         }
     }
-    const bool closes = m == 63;   // this wave speaks for its group
-    if (closes && lane == 0)
-        __hip_atomic_store(&gs[g], kStatusCount | (within + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint64_t front = 0;    // newlines in front of this group
-    if (g) {
-        int64_t pos = (int64_t)g - 1;
-        for (;;) {   // 64 groups at a time, nearest in lane 0
-            const int64_t idx = pos - lane;
-            uint64_t st = kStatusPrefix;   // in front of the text: prefix 0
-            if (idx >= 0) st = __hip_atomic_load(&gs[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint64_t isP = __ballot((st >> 62) == 2), isX = __ballot((st >> 62) == 0);
-            const int firstP = isP ? __builtin_ctzll(isP) : 64;
-            const uint64_t upto = firstP >= 63 ? ~0ull : ((2ull << firstP) - 1ull);
-            if (isX & upto) { __builtin_amdgcn_s_sleep(1); continue; }   // a group in between has not closed yet
-            front += wave_sum_u64(lane <= firstP ? (st & kStatusValue) : 0);
-            if (firstP != 64) break;
-            pos -= 64;
-        }
+    cnt = wave_sum_u32(cnt);
+    if (lane == 0) {
+        counts[chunk] = cnt;
+        n_entries[chunk] = ne;
+        if (ne > (uint32_t)kNlEntries) atomicAdd((unsigned long long*)overflow, 1ull);
     }
-    const uint64_t excl = front + within;
-    if (closes && lane == 0)
-        __hip_atomic_store(&gs[g], kStatusPrefix | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (chunk == n_chunks - 1 && lane == 0) status[n_chunks + 1] = excl + mine;
-    // place the line starts: the k-th newline of the text (0-based) at byte p sets line_off[k + 1] = p + 1
-    uint64_t base = excl;
+}
+
+constexpr int kScanBlock = 2048;   // entries per block of the two-level scan
+uint64_t nl_scan_block_words(uint64_t n_chunks) { return (n_chunks + kScanBlock - 1) / kScanBlock + 2; }
+
+__global__ __launch_bounds__(256) void nl_blocksum_kernel(const uint32_t* __restrict__ counts, uint64_t n,
+                                                          uint64_t* __restrict__ bsum) {
+    __shared__ unsigned long long acc;
+    if (threadIdx.x == 0) acc = 0;
+    __syncthreads();
+    uint64_t t = 0;
+    for (int k = 0; k < kScanBlock / 256; ++k) {
+        const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)k * 256 + threadIdx.x;
+        if (i < n) t += counts[i];
+    }
+    t = wave_sum_u64(t);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&acc, (unsigned long long)t);
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = acc;
+}
+
+// single block: exclusive scan of the block sums in place; grand total -> *total
+__global__ __launch_bounds__(256) void nl_scan_top_kernel(uint64_t* __restrict__ bsum, uint64_t nblocks,
+                                                          uint64_t* __restrict__ total) {
+    __shared__ uint64_t part[256];
+    const uint32_t t = threadIdx.x;
+    const uint64_t seg = (nblocks + 255) / 256;
+    const uint64_t b = t * seg, e = b + seg < nblocks ? b + seg : nblocks;
+    uint64_t s = 0;
+    for (uint64_t i = b; i < e; ++i) s += bsum[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 256; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    uint64_t run = part[t];
+    for (uint64_t i = b; i < e; ++i) { const uint64_t v = bsum[i]; bsum[i] = run; run += v; }
+}
+
+// per block of kScanBlock entries: thread owns 8 consecutive entries
+__global__ __launch_bounds__(256) void nl_scan_apply_kernel(const uint32_t* __restrict__ counts, uint64_t n,
+                                                            const uint64_t* __restrict__ bsum,
+                                                            uint64_t* __restrict__ prefix) {
+    __shared__ uint64_t part[256];
+    const uint32_t t = threadIdx.x;
+    const uint64_t b0 = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)t * 8;
+    uint32_t v[8];
+    uint64_t loc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = b0 + k < n ? counts[b0 + k] : 0; loc += v[k]; }
+    part[t] = loc;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t run = bsum[blockIdx.x];
+        for (int i = 0; i < 256; ++i) { const uint64_t x = part[i]; part[i] = run; run += x; }
+    }
+    __syncthreads();
+    uint64_t run = part[t];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (b0 + k < n) prefix[b0 + k] = run;
+        run += v[k];
+    }
+}
+
+
+// half a wave per chunk: lane j of the half owns the chunk's j-th odd vector
+__global__ __launch_bounds__(256) void nl_place_kernel(const uint64_t* __restrict__ prefix, const uint32_t* __restrict__ n_entries,
+                                                       const uint64_t* __restrict__ entries, uint64_t n_chunks,
+                                                       uint64_t* __restrict__ line_off, uint64_t n, uint64_t n_lines,
+                                                       uint64_t* __restrict__ errors) {
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const uint64_t chunk = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (uint64_t)(lane >> 5);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { line_off[0] = 0; line_off[n_lines] = n; }
+    const bool live = chunk < n_chunks;
+    const uint32_t ne = live ? n_entries[chunk] : 0;
+    const uint64_t e = (live && (uint32_t)j < ne) ? entries[chunk * kNlEntries + j] : 0;
+    uint32_t bits = (uint32_t)e & 0xFFFFu;
+    const uint32_t bad = (uint32_t)(e >> 16) & 0xFFFFu;
+    const uint32_t c = __popc(bits);
+    // exclusive prefix of the newline counts inside each half: the full-wave scan, minus what the lower half added
+    const uint32_t inc = wave_scan_incl_u32(c);
+    const uint32_t low = (uint32_t)__builtin_amdgcn_readlane((int)inc, 31);
+    uint64_t k = (live ? prefix[chunk] : 0) + (inc - c) - (lane >= 32 ? low : 0u);   // the line the vector starts in
+    const uint64_t pos = chunk * kNlChunk + (uint64_t)(uint32_t)(e >> 32) * kVec;
     uint32_t nbad = 0;
+    // quality lines are the lines 3 (mod 4): count their invalid bytes (what SeqIO rejects, lib/seq_routines.py:50)
+    for (uint32_t m = bad; m; m &= m - 1) {
+        const int b = __ffs((int)m) - 1;
+        nbad += ((k + __popc(bits & ((1u << b) - 1u))) & 3) == 3;
+    }
+    while (bits) {
+        const int b = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        if (k + 1 < n_lines) line_off[k + 1] = pos + (uint64_t)b + 1;   // a final newline at n - 1 is line_off[n_lines] = n
+        ++k;
+    }
+    nbad = wave_sum_u32(nbad);
+    if (lane == 0 && nbad) atomicAdd((unsigned long long*)&errors[3], (unsigned long long)nbad);
+}
+
+// one wave per chunk again: the k-th newline of the text (0-based) at byte p sets line_off[k + 1] = p + 1
+__global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                      const uint64_t* __restrict__ prefix, uint64_t n_chunks,
+                                                      uint64_t* __restrict__ line_off, uint64_t n_lines,
+                                                      uint64_t* __restrict__ errors) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { line_off[0] = 0; line_off[n_lines] = n; }
+    if (chunk >= n_chunks) return;
+    uint64_t base = uniform_u64(prefix[chunk]);
+    uint32_t nbad = 0;
+    constexpr int kIt = (int)(kNlChunk / kSpan);
+    uint4 vv[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {   // all loads of the chunk in flight before the first use
+        const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
+        vv[it] = load_vec_clamped(text, pos < n ? pos : 0, n);
+    }
 #pragma unroll
     for (int it = 0; it < kIt; ++it) {
         const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
-        uint32_t bits = nlb[it], bad = 0;
+        uint32_t bits = 0, bad = 0;
+        // nearly every vector holds only '!'..'~' bytes: one cheap test, the exact masks only where it fires
         const uint4& v = vv[it];
         if (pos < n && (odd_byte_mask(v.x) | odd_byte_mask(v.y) | odd_byte_mask(v.z) | odd_byte_mask(v.w))) {
             const uint64_t rem = n - pos;
+            bits = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
             bad = vec_badq_bits(v, rem < 16 ? (int)rem : 16);
         }
-        const uint32_t c = __popc(bits);
-        uint32_t inc = c;   // inclusive wave prefix of the lane counts
+        const uint32_t cnt = __popc(bits);
+        uint32_t inc = cnt;   // inclusive wave prefix of the lane counts
         if (__ballot(bits != 0) != 0) {   // most 1 KiB spans lie inside one line: no newline, nothing to scan
-            inc = wave_scan_incl_u32(c);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(inc, o);
+                if (lane >= o) inc += u;
+            }
         }
-        uint64_t k = base + (inc - c);   // number of the line the vector starts in
+        uint64_t k = base + (inc - cnt);   // number of the line the vector starts in
         // quality lines are the lines 3 (mod 4): count their invalid bytes (what SeqIO rejects, lib/seq_routines.py:50)
         if (bad) {
             if (!bits) nbad += (k & 3) == 3 ? __popc(bad) : 0;
@@ -193,26 +286,46 @@ __global__ __launch_bounds__(64 * kNlWaves) void nl_index_kernel(const uint8_t* 
         while (bits) {
             const int b = __ffs((int)bits) - 1;
             bits &= bits - 1;
-            if (k + 1 <= line_cap) line_off[k + 1] = pos + (uint64_t)b + 1;   // beyond the table's capacity: counted only
+            if (k + 1 < n_lines) line_off[k + 1] = pos + (uint64_t)b + 1;   // a final newline at n - 1 is line_off[n_lines] = n
             ++k;
         }
         base += (uint32_t)__shfl((int)inc, 63);
     }
-    nbad = wave_sum_u32(nbad);
+    nbad = (uint32_t)wave_sum_u64(nbad);
     if (lane == 0 && nbad) atomicAdd((unsigned long long*)&errors[3], (unsigned long long)nbad);
 }
 
-uint64_t nl_status_words(uint64_t n_chunks) { return n_chunks + 2 + (n_chunks + 63) / 64; }
 
-// status: nl_status_words(n_chunks) u64.  Leaves line_off[0 .. min(lines, line_cap)] and the number of newlines in
-// status[n_chunks + 1]; the caller sets line_off[n_lines] = n for a text without a final newline.
-hipError_t launch_nl_index(const uint8_t* text, uint64_t n, uint64_t* status, uint64_t* line_off, uint64_t line_cap,
+// Pass 1 and the scan: counts, entries and the chunks' line numbers; fs.prefix[n_chunks] = newlines of the text,
+// fs.prefix[n_chunks + 1] = chunks whose entry list overflowed.
+hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, hipStream_t s) {
+    const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
+    hipError_t e = hipMemsetAsync(fs.prefix + n_chunks, 0, 16, s);
+    if (e != hipSuccess || n_chunks == 0) return e;
+    hipLaunchKernelGGL(nl_scan_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, text, n, fs.counts, fs.n_entries,
+                       fs.entries, n_chunks, fs.prefix + n_chunks + 1);
+    const uint64_t nblocks = (n_chunks + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(nl_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, fs.counts, n_chunks, fs.block_sums);
+    hipLaunchKernelGGL(nl_scan_top_kernel, dim3(1), dim3(256), 0, s, fs.block_sums, nblocks, fs.prefix + n_chunks);
+    hipLaunchKernelGGL(nl_scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, fs.counts, n_chunks,
+                       fs.block_sums, fs.prefix);
+    return hipGetLastError();
+}
+
+// line_off[0] = 0, line_off[k + 1] = position after the k-th newline, line_off[n_lines] = n; errors[3] += bytes of quality
+// lines outside '!'..'~' (white space excepted).  `sparse`: from the entries of pass 1; else by a second pass over the text.
+hipError_t launch_nl_place(const uint8_t* text, uint64_t n, uint64_t n_lines, bool sparse, const FastqScratch& fs,
                            uint64_t* errors, hipStream_t s) {
     const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
-    hipError_t e = hipMemsetAsync(status, 0, nl_status_words(n_chunks) * 8, s);
-    if (e != hipSuccess || n_chunks == 0) return e;
-    hipLaunchKernelGGL(nl_index_kernel, dim3((unsigned)((n_chunks + kNlWaves - 1) / kNlWaves)), dim3(64 * kNlWaves), 0, s, text, n, status, n_chunks,
-                       line_off, line_cap, errors);
+    if (sparse) {
+        const uint64_t blocks = n_chunks ? (n_chunks + 7) / 8 : 1;
+        hipLaunchKernelGGL(nl_place_kernel, dim3((unsigned)blocks), dim3(256), 0, s, fs.prefix, fs.n_entries, fs.entries,
+                           n_chunks, fs.line_off, n, n_lines, errors);
+    } else {
+        const uint64_t blocks = n_chunks ? (n_chunks + 3) / 4 : 1;
+        hipLaunchKernelGGL(nl_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, text, n, fs.prefix, n_chunks, fs.line_off,
+                           n_lines, errors);
+    }
     return hipGetLastError();
 }
 
@@ -256,6 +369,32 @@ __device__ inline int64_t parse_iso8601(const uint8_t* __restrict__ t, uint64_t 
         return INT64_MIN;
     if (f[1] < 1 || f[1] > 12 || f[2] < 1 || f[2] > 31) return INT64_MIN;
     return days_from_civil(f[0], (unsigned)f[1], (unsigned)f[2]) * 86400 + f[3] * 3600 + f[4] * 60 + f[5];
+}
+
+// The albacore header fields (the reference reads ch= at lib/seq_routines.py:51) need the line table only, not the sums: a
+// kernel of its own that runs beside the line-mode tile kernel on the auxiliary stream.  One thread per record walks its
+// header byte by byte (about 150 dependent loads: 0.15 of the 0.19 ms fastq_finalize took for 200 000 records when it did
+// this behind the tile kernel).  fastq_finalize overrides both fields for a malformed record.
+__global__ __launch_bounds__(256) void fastq_header_kernel(const uint8_t* __restrict__ text, uint64_t n_records,
+                                                           const uint64_t* __restrict__ lo, ReadArrays ra,
+                                                           uint64_t read_base, uint8_t mux) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_records) return;
+    const uint64_t g = read_base + r;
+    const uint64_t a = lo[4 * r];
+    uint64_t e = lo[4 * r + 1];
+    while (e > a && is_space(text[e - 1])) --e;
+    uint32_t ch = 0;
+    int64_t tm = INT64_MIN;
+    if (e > a) {
+        uint64_t p = find_field(text, a + 1, e, "ch=", 3);
+        for (; p < e && text[p] >= '0' && text[p] <= '9'; ++p) ch = ch * 10 + (uint32_t)(text[p] - '0');
+        p = find_field(text, a + 1, e, "start_time=", 11);
+        if (p < e) tm = parse_iso8601(text, p, e);
+    }
+    ra.channel[g] = ch;
+    ra.mux[g] = mux;
+    ra.time[g] = tm;
 }
 
 __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __restrict__ text, uint64_t n,
@@ -315,18 +454,18 @@ __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __re
     ra.err_hi[g] = hi; ra.err_lo[g] = lw;
     ra.mean_q[g] = mq;
     ra.flags[g] = flags;
-    // albacore header fields (the reference reads ch= at lib/seq_routines.py:51)
-    uint32_t ch = 0;
-    int64_t tm = INT64_MIN;
-    if (ok) {
-        uint64_t p = find_field(text, a[0] + 1, e[0], "ch=", 3);
-        for (; p < e[0] && text[p] >= '0' && text[p] <= '9'; ++p) ch = ch * 10 + (uint32_t)(text[p] - '0');
-        p = find_field(text, a[0] + 1, e[0], "start_time=", 11);
-        if (p < e[0]) tm = parse_iso8601(text, p, e[0]);
+    if (!ok) {   // fastq_header_kernel has parsed the header of what is no record
+        ra.channel[g] = 0;
+        ra.time[g] = INT64_MIN;
     }
-    ra.channel[g] = ch;
-    ra.mux[g] = mux;
-    ra.time[g] = tm;
+}
+
+hipError_t launch_fastq_header(const uint8_t* text, uint64_t n_records, const uint64_t* line_off, ReadArrays ra,
+                               uint64_t read_base, uint8_t mux, hipStream_t s) {
+    if (n_records == 0) return hipSuccess;
+    hipLaunchKernelGGL(fastq_header_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n_records,
+                       line_off, ra, read_base, mux);
+    return hipGetLastError();
 }
 
 hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,

@@ -151,18 +151,25 @@ hipError_t launch_select_pick(uint64_t* sel, const uint64_t* total, uint64_t* st
                               bool first, uint64_t* out, hipStream_t s);   // total == nullptr: from the first round's histogram
 
 // ---- FASTQ text on the GPU (ppqc_fastq_gpu.hip) --------------------------------------------------------------------
-constexpr uint32_t kNlChunk = 8192;   // bytes of text per wave of the line-index kernel (eight 1 KiB spans in registers)
+constexpr uint32_t kNlChunk = 8192;   // bytes of text per wave of the line-index kernels (eight 1 KiB spans in registers)
+constexpr uint32_t kNlEntriesPerChunk = 32;
 struct FastqScratch {
-    uint64_t* status;       // chained-scan words of the line-index kernel (nl_status_words)
+    uint32_t* counts;       // newlines per chunk
+    uint32_t* n_entries;    // odd vectors per chunk (may exceed kNlEntriesPerChunk: then the list is incomplete)
+    uint64_t* entries;      // kNlEntriesPerChunk per chunk
+    uint64_t* prefix;       // exclusive prefix of counts; [n_chunks] = newlines of the text, [n_chunks + 1] = overflowing chunks
+    uint64_t* block_sums;   // scan scratch
     uint64_t* line_off;     // n_lines + 1 line starts (the CSR offsets of the line-mode tile kernel)
 };
-uint64_t nl_status_words(uint64_t n_chunks);
-// line_off[0] = 0, line_off[k + 1] = position after the k-th newline for k + 1 <= line_cap; the number of newlines lands
-// in status[n_chunks + 1].  Also counts, in errors[3], the bytes of quality lines outside '!'..'~' (white space excepted).
-hipError_t launch_nl_index(const uint8_t* text, uint64_t n, uint64_t* status, uint64_t* line_off, uint64_t line_cap,
+uint64_t nl_scan_block_words(uint64_t n_chunks);
+hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, hipStream_t s);
+hipError_t launch_nl_place(const uint8_t* text, uint64_t n, uint64_t n_lines, bool sparse, const FastqScratch& fs,
                            uint64_t* errors, hipStream_t s);
 // one thread per record: validates the four lines, strips line ends, merges the line sums into the per-read arrays,
 // parses ch= and start_time= out of the header.  errors[1] counts malformed records.
+// channel, mux and start time of every record from its header line (needs the line table only)
+hipError_t launch_fastq_header(const uint8_t* text, uint64_t n_records, const uint64_t* line_off, ReadArrays ra,
+                               uint64_t read_base, uint8_t mux, hipStream_t s);
 hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
                                  ReadArrays line_ra, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint32_t tile_shift, const uint64_t* lut, uint64_t thr_fail,

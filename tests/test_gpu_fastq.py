@@ -154,11 +154,12 @@ def test_invalid_quality_bytes_are_counted_like_the_host_packer(qc_mod):
         assert ctx.input_errors()["bad_quality_bytes"] == 0
 
 
-def test_dense_text_grows_the_line_table_and_counts_once(qc_mod, c_oracle):
-    """The line table is sized before the lines are counted (64 bytes per line to begin with).  Reads of a few bases
-    give four lines in about 40 bytes: the single-pass index kernel then counts more lines than the table holds, the
-    table grows and the pass runs again -- with the same records, tables and invalid-quality-byte count as the host
-    packer, not twice the count.  A second, sparser text on the same context then fits at once."""
+def test_dense_text_takes_the_second_text_pass(qc_mod, c_oracle):
+    """The first pass over the text notes at most 32 vectors per 8 KiB chunk that hold a line end or an invalid quality
+    byte, and the line starts are placed from those notes.  Reads of a few bases give a line end in every other vector:
+    the lists overflow and the line starts come from a second pass over the text instead -- same records, tables and
+    invalid-quality-byte count as the host packer either way.  A sparser text on the same context then goes back to the
+    notes."""
     from pypore_amd import fastq_io
     rng = np.random.default_rng(12)
     recs = []
