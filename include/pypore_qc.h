@@ -328,6 +328,20 @@ typedef struct ppqc_mode1_tables {
 int ppqc_mode1_dist_view(ppqc_ctx* ctx, ppqc_mode1_tables* out);
 int ppqc_mode1_dist_phase(ppqc_ctx* ctx, int phase);
 
+/* Several GPUs driven by ONE process, without torch: the counterpart of gathering the workers' results over the result
+ * queue and summing over channels (lib/seq_routines.py:940-942, :103-108) for a caller that binds this library through
+ * ctypes / cgo / JNI and has no collective library of its own.  ppqc_group_create takes n contexts on n different GPUs
+ * and opens an RCCL communicator over them (ncclCommInitAll; librccl is loaded with dlopen at this call, so the
+ * library itself has no link-time dependency on it: PPQC_E_NO_DEVICE if it cannot be loaded).  ppqc_group_finalize runs
+ * the phased finalize on every context with the all-reduces in between -- MAX over [max_buf | min_buf], in time_mode 1
+ * the three merges of ppqc_mode1_dist_phase, SUM over [sum_buf | sel_buf] and the two further N50-select rounds --
+ * each on its context's stream, and fetches the merged tables (the same on every context) from the first one.
+ * One process per GPU over torch.distributed is the other way (pypore_amd/merge.py); both enqueue the same kernels. */
+typedef struct ppqc_group ppqc_group;
+int ppqc_group_create(ppqc_group** out, ppqc_ctx* const* ctxs, int n);
+int ppqc_group_finalize(ppqc_group* group, ppqc_tables* out);
+int ppqc_group_destroy(ppqc_group* group);
+
 /* Enqueue all further work of the context on a caller-owned HIP stream (use_external != 0; `stream` is a hipStream_t,
  * 0 = the null stream) so that it is stream-ordered with the caller's own kernels and RCCL collectives without host
  * synchronisation, or go back to the context's own stream (use_external == 0).  Drains the previous stream first. */

@@ -2,6 +2,7 @@
 // Owns all device memory, one compute stream and two copy streams (double-buffered H2D) per context.
 #include <math.h>
 #include <stdio.h>
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -103,6 +104,8 @@ struct ppqc_ctx {
     bool res_clean = false;  // ppqc_reset cleared the result buffer on the main stream and nothing has used it since
     hipEvent_t fin_start = nullptr, sort_start = nullptr;   // start events of the finalize / sort timings of this step
     bool fin_pending = false; // the last finalize's events have not been turned into timings yet
+    uint64_t reads_gen = 0, fin_gen = 0;   // ev_reads is recorded per batch and doubles as the start of a finalize's timings:
+                                           // its generation then and at resolve time tell whether it still is that start
     bool end_split = false;  // the finalize ended on two streams: its end is the later of ev_t1 and sort_end
     bool res_busy = false;   // a finalize phase (or a caller's collective on the tables) may still run: set by every
                              // finalize phase, cleared when the stream has been synchronised
@@ -562,6 +565,7 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     // nothing to do while this batch runs
     if (c->n_reads == 0) CHK(resolve_batch_timings(c, prev_a, true));
     HIPCHK(hipEventRecord(c->ev_reads, s));
+    ++c->reads_gen;
     c->n_reads += R;
     c->state = 0;
     c->n50_early = false;
@@ -767,6 +771,8 @@ static void resolve_finalize_timings(ppqc_ctx* c) {
     c->fin_pending = false;
     float ms = 0.f;
     hipEvent_t f0 = c->fin_start ? c->fin_start : c->ev_t0, s0 = c->sort_start ? c->sort_start : c->ev_s0;
+    // a batch submitted since that finalize has recorded ev_reads again: the interval is gone, the last figures stay
+    if ((f0 == c->ev_reads || s0 == c->ev_reads) && c->fin_gen != c->reads_gen) return;
     if (hipEventElapsedTime(&ms, f0, c->ev_t1) == hipSuccess) {
         float ms2 = 0.f;
         if (c->end_split && c->sort_end && hipEventElapsedTime(&ms2, f0, c->sort_end) == hipSuccess && ms2 > ms) ms = ms2;
@@ -868,6 +874,7 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     resolve_finalize_timings(c);   // its events are about to be recorded again
+    c->fin_gen = c->reads_gen;
     c->sum_fetched = false;
     c->m1_phase = -1;
     // The result buffer is cleared on the auxiliary stream: this call is usually enqueued while the per-read kernels of
@@ -1204,6 +1211,146 @@ int ppqc_mode1_dist_phase(ppqc_ctx* c, int phase) {
     HIPCHK(launch_mode1_dist(phase, c->ra, c->n_reads, c->tp, c->m1, c->stream));
     c->m1_phase = phase;
     return mark_busy(c);
+}
+
+// ---- one process, several GPUs: RCCL through dlopen ---------------------------------------------------------------------
+namespace {
+typedef void* nccl_comm;
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(nccl_comm*, int, const int*) = nullptr;
+    int (*CommDestroy)(nccl_comm) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclInt64 = 4, kNcclUint64 = 5, kNcclSum = 0, kNcclMax = 2;   // rccl.h: ncclDataType_t, ncclRedOp_t
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+int load_rccl() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return PPQC_OK;
+    // a librccl already in the process (torch brings its own) is found first by its soname
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names)
+        if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return fail(PPQC_E_NO_DEVICE, std::string("librccl could not be loaded: ") + dlerror());
+    Rccl r;
+    r.lib = h;
+    r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString)
+        return fail(PPQC_E_NO_DEVICE, "librccl lacks an expected symbol");
+    g_rccl = r;
+    return PPQC_OK;
+}
+}  // namespace
+
+struct ppqc_group {
+    std::vector<ppqc_ctx*> ctx;
+    std::vector<nccl_comm> comm;
+};
+
+#define NCCLCHK(expr)                                                                                       \
+    do {                                                                                                    \
+        int e_ = (expr);                                                                                    \
+        if (e_ != 0) return fail(PPQC_E_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(e_));       \
+    } while (0)
+
+// one all-reduce, in place, of `count` 64-bit words at the same place of every context (picked by `where`)
+typedef uint64_t* (*group_where)(ppqc_ctx*, uint64_t);
+static uint64_t* at_maxmin(ppqc_ctx* c, uint64_t) { return c->max_buf; }
+static uint64_t* at_sum(ppqc_ctx* c, uint64_t) { return c->sum_buf; }
+static uint64_t* at_sel(ppqc_ctx* c, uint64_t) { return c->sel_buf; }
+static uint64_t* at_m1(ppqc_ctx* c, uint64_t off) { return c->m1 + off; }
+static int group_all_reduce(ppqc_group* g, group_where where, uint64_t off, uint64_t count, int op) {
+    if (count == 0) return PPQC_OK;
+    NCCLCHK(g_rccl.GroupStart());
+    for (size_t k = 0; k < g->ctx.size(); ++k) {
+        void* p = where(g->ctx[k], off);
+        const int e = g_rccl.AllReduce(p, p, (size_t)count, op == kNcclSum ? kNcclUint64 : kNcclInt64, op, g->comm[k],
+                                       g->ctx[k]->stream);
+        if (e != 0) { (void)g_rccl.GroupEnd(); return fail(PPQC_E_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(e)); }
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    for (ppqc_ctx* c : g->ctx) c->res_busy = true;
+    return PPQC_OK;
+}
+
+int ppqc_group_create(ppqc_group** out, ppqc_ctx* const* ctxs, int n) {
+    if (!out || !ctxs || n < 1) return fail(PPQC_E_INVALID, "null argument or no context");
+    *out = nullptr;
+    std::vector<int> devs;
+    for (int k = 0; k < n; ++k) {
+        if (!ctxs[k]) return fail(PPQC_E_INVALID, "null context in the group");
+        for (int d : devs)
+            if (d == ctxs[k]->device) return fail(PPQC_E_INVALID, "two contexts of a group on one GPU");
+        devs.push_back(ctxs[k]->device);
+        const ppqc_config &a = ctxs[0]->cfg, &b = ctxs[k]->cfg;
+        if (a.n_channels != b.n_channels || a.n_mux != b.n_mux || a.n_time_bins != b.n_time_bins ||
+            a.bin_seconds != b.bin_seconds || a.time_mode != b.time_mode || a.tz_offset_s != b.tz_offset_s ||
+            a.fail_q != b.fail_q || a.compat_flags != b.compat_flags)
+            return fail(PPQC_E_INVALID, "the contexts of a group must share one configuration");
+    }
+    CHK(load_rccl());
+    ppqc_group* g = new (std::nothrow) ppqc_group();
+    if (!g) return fail(PPQC_E_NOMEM, "out of host memory");
+    g->ctx.assign(ctxs, ctxs + n);
+    g->comm.assign(n, nullptr);
+    const int e = g_rccl.CommInitAll(g->comm.data(), n, devs.data());
+    if (e != 0) {
+        delete g;
+        return fail(PPQC_E_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(e));
+    }
+    *out = g;
+    return PPQC_OK;
+}
+
+int ppqc_group_destroy(ppqc_group* g) {
+    if (!g) return PPQC_OK;
+    for (size_t k = 0; k < g->comm.size(); ++k) {
+        (void)hipSetDevice(g->ctx[k]->device);
+        (void)hipStreamSynchronize(g->ctx[k]->stream);
+        if (g->comm[k]) (void)g_rccl.CommDestroy(g->comm[k]);
+    }
+    delete g;
+    return PPQC_OK;
+}
+
+int ppqc_group_finalize(ppqc_group* g, ppqc_tables* out) {
+    if (!g || !out) return fail(PPQC_E_INVALID, "null argument");
+    const uint64_t nch1 = 1 + (uint64_t)g->ctx[0]->cfg.n_channels, nch = g->ctx[0]->cfg.n_channels;
+    const uint64_t n_sum = g->ctx[0]->tp.lay.n_sum;
+    int64_t ref = g->ctx[0]->tp.ref_time_s;
+    for (ppqc_ctx* c : g->ctx) {
+        if (c->tp.ref_time_s != ref) return fail(PPQC_E_INVALID, "the contexts of a group must share one reference time");
+        CHK(ppqc_finalize_extremes(c));
+    }
+    CHK(group_all_reduce(g, at_maxmin, 0, 2 * nch1, kNcclMax));
+    if (g->ctx[0]->cfg.time_mode == 1) {
+        for (ppqc_ctx* c : g->ctx) { ppqc_mode1_tables v; CHK(ppqc_mode1_dist_view(c, &v)); CHK(ppqc_mode1_dist_phase(c, 0)); }
+        CHK(group_all_reduce(g, at_m1, 0, nch, kNcclMax));
+        for (ppqc_ctx* c : g->ctx) CHK(ppqc_mode1_dist_phase(c, 1));
+        CHK(group_all_reduce(g, at_m1, nch, nch + 1, kNcclSum));
+        CHK(group_all_reduce(g, at_m1, 2 * nch + 1, 2 * nch * PPQC_MODE1_DAYS, kNcclMax));
+        for (ppqc_ctx* c : g->ctx) CHK(ppqc_mode1_dist_phase(c, 2));
+    }
+    for (ppqc_ctx* c : g->ctx) CHK(ppqc_finalize_tables(c));
+    for (int r = 0; r < 3; ++r) {
+        for (ppqc_ctx* c : g->ctx) CHK(ppqc_n50_select_hist(c, r));
+        if (r == 0) CHK(group_all_reduce(g, at_sum, 0, n_sum + PPQC_N_SEL, kNcclSum));
+        else CHK(group_all_reduce(g, at_sel, 0, PPQC_N_SEL, kNcclSum));
+        for (ppqc_ctx* c : g->ctx) CHK(ppqc_n50_select_pick(c, r));
+    }
+    for (size_t k = 1; k < g->ctx.size(); ++k) CHK(ppqc_sync(g->ctx[k]));
+    return ppqc_fetch_tables(g->ctx[0], out);
 }
 
 int ppqc_set_stream(ppqc_ctx* c, void* stream, int use_external) {

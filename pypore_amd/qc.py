@@ -348,6 +348,36 @@ class QCContext:
         L.check(self._lib.ppqc_synth_fill_device(self._ctx, bases_ptr, quals_ptr, int(first), int(n), int(seed)))
 
 
+class Group:
+    """Several contexts on several GPUs of ONE process, merged by the library itself over RCCL (ppqc_group_*): what a
+    binding without torch uses.  ``finalize()`` returns the merged tables of the job."""
+
+    def __init__(self, contexts):
+        self._lib = L.load()
+        self.contexts = list(contexts)
+        arr = (C.c_void_p * len(self.contexts))(*[c._ctx for c in self.contexts])
+        self._g = C.c_void_p()
+        L.check(self._lib.ppqc_group_create(C.byref(self._g), arr, len(self.contexts)))
+
+    def finalize(self):
+        arr, t = self.contexts[0]._alloc_tables()
+        L.check(self._lib.ppqc_group_finalize(self._g, C.byref(t)))
+        for c in self.contexts:
+            c._keep.clear()
+        return QCContext._tables_dict(arr, t)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._lib.ppqc_group_destroy(self._g)
+            self._g = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class PinnedBuffer:
     """Page-locked host memory from ``ppqc_alloc_pinned`` viewed as a numpy uint8 array: batches sliced out of it
     are copied by DMA, asynchronously, in ``submit`` (the loaders' double buffer of BASELINE config 5)."""

@@ -112,6 +112,32 @@ def test_mode1_phases_equal_the_sort_based_hours(qc_mod, c_oracle):
             ctx.fetch_tables()
 
 
+def test_group_finalize_without_torch_collectives(qc_mod, c_oracle):
+    """ppqc_group_*: the library's own RCCL merge for one process that drives several GPUs (librccl through dlopen, no torch
+    in the call path).  One GPU here, so a group of one context -- every collective runs, over a single rank -- in both
+    time modes, against ppqc_finalize on the same reads and the oracle; a second finalize of the group after more reads."""
+    from pypore_amd._lib import PPQCError
+    for mode in (0, 1):
+        cfg = dict(n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=mode, tz_offset_s=3600,
+                   ref_time_s=1_528_000_000, fail_q=7.0)
+        b = random_batch(41 + mode, 8000, 500, hours=46)
+        args = (b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], b["fail_flag"])
+        with qc_mod.QCContext(device=0, **cfg) as ctx, qc_mod.QCContext(device=0, **cfg) as single:
+            single.submit(*args)
+            want = single.finalize()
+            with qc_mod.Group([ctx]) as grp:
+                ctx.submit(*args)
+                got = grp.finalize()
+                assert_tables_equal(got, want, "group of one, time_mode %d" % mode)
+                ctx.submit(*args)                       # more reads behind a group finalize
+                single.submit(*args)
+                assert_tables_equal(grp.finalize(), single.finalize(), "second group finalize")
+            with pytest.raises(PPQCError, match="one GPU"):
+                qc_mod.Group([ctx, single])
+        w = c_oracle.per_read(b["bases"], b["quals"], b["offsets"], nthreads=4)
+        assert_tables_equal(got, c_oracle.tables(w, b["channel"], b["mux"], b["time"], b["fail_flag"], cfg))
+
+
 def test_two_ranks_on_one_gpu_over_gloo():
     """tools/dist_rehearsal.py: world_size 2 (two processes sharing the one GPU, gloo because RCCL refuses two ranks on a
     device): early, phased and gather merge and an empty shard on one rank, every rank's tables against the host merge
