@@ -171,6 +171,7 @@ struct TileCtx {
     int lane;
     uint32_t lane_off;
     uint32_t* xs;   // 64 words of LDS per wave (boundary_rounds)
+    bool line;      // line mode (FASTQ text): the sums of header and '+' lines (even line numbers) are never read
 };
 
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
@@ -226,6 +227,10 @@ __device__ __forceinline__ void walk_advance(Walk& w, const TileCtx& c) {
 }
 
 __device__ __forceinline__ void flush_read(Acc& acc, const Walk& w, const TileCtx& c) {
+    if (c.line && !(w.r & 1)) {   // a header or '+' line: nothing of it is wanted, so no reduction and no store
+        acc = Acc{0, 0, 0, 0};
+        return;
+    }
     // a read that ends here is complete if it also started in this tile, else this is the head partial of the tile
     const bool whole = w.rs >= c.tile_start;
     Partial* p = &c.head[c.t];
@@ -521,7 +526,7 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
     const uint64_t kTile = 1ull << b.tile_shift;
     TileCtx c;
     c.read_base = read_base; c.R = b.n_reads; c.off = b.offsets; c.ra = ra; c.head = head; c.lut = lut;
-    c.lane = lane; c.lane_off = (uint32_t)lane * kVec; c.xs = &xs[wib][0];
+    c.lane = lane; c.lane_off = (uint32_t)lane * kVec; c.xs = &xs[wib][0]; c.line = LINE;
 
     for (uint64_t t = (uint64_t)blockIdx.x * 4 + wib; t < n_tiles; t += n_waves) {
         const uint64_t tile_start = t << b.tile_shift;
@@ -582,7 +587,7 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
             }
         }
         // a read that continues into the next tile leaves a partial: tail if it started here, else head
-        if (!w.done && w.rs < tile_start + kTile && w.re > tile_start + kTile) {
+        if (!w.done && w.rs < tile_start + kTile && w.re > tile_start + kTile && !(LINE && !(w.r & 1))) {
             Partial* p = w.rs >= tile_start ? &tail[t] : &head[t];
             flush(acc, lane, &p->cnt, &p->hi, &p->lo);
         }
@@ -889,7 +894,7 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
     if ((uint64_t)blockIdx.x * 4 >= count) return;   // whole block: nothing below needs a block-level barrier
     TileCtx c;
     c.read_base = read_base; c.R = b.n_reads; c.off = b.offsets; c.ra = ra; c.head = head; c.lut = lut;
-    c.lane = lane; c.lane_off = (uint32_t)lane * kVec; c.xs = &xs[wib][0];
+    c.lane = lane; c.lane_off = (uint32_t)lane * kVec; c.xs = &xs[wib][0]; c.line = false;   // (every line's sums are stored here)
     uint4* __restrict__ gb = &cutb[wib][0];
     uint4* __restrict__ gq = &cutq[wib][0];
     uint32_t* __restrict__ gx = &cutx[wib][0];
