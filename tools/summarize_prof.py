@@ -39,7 +39,9 @@ def pmc_means(d, counter):
 
 def per_step(means):
     """Sum over the per-read kernels of (mean x dispatches), per tile_kernel dispatch (= per step)."""
-    steps = max([v["dispatches"] for k, v in means.items() if "tile_kernel" in k] or [0])
+    # one launch per step of tile_kernel (with dense_kernel behind it) or, for a batch that is dense on average, of
+    # dense_kernel alone
+    steps = max([v["dispatches"] for k, v in means.items() if any(p in k for p in PER_READ)] or [0])
     if not steps:
         return None
     return sum(v["mean_KB"] * v["dispatches"] for k, v in means.items() if any(p in k for p in PER_READ)) * 1024 / steps
