@@ -845,34 +845,47 @@ __device__ __forceinline__ uint64_t win_ends(const Win2& W, uint64_t r, int lane
 // n_reads / T + 1 entries and the grid is sized by that bound: waves beyond the count leave at once (config 2: 15 000
 // waves, 4 us).  counters[parity] is this launch's count; the other counter, last used by the previous launch (complete:
 // stream order) and next by the following one, is put back to zero here (64 counters per parity: see DenseOut).
+// ALL: a batch that is dense on average is launched as dense_kernel<.., true> alone: one wave per tile of the batch, no
+// list (tile_kernel's pass over it would do nothing but probe and append: 0.21 of 1.40 ms at a mean of 500 B), the first
+// read by the same 64-ary search.
 //
 // ENTRY SPACE.  The read ends inside a span are taken in read order, one lane each: lane j holds the j-th end p_j of the
-// span (from the window registers), the vector it cuts v_j = (p_j - span_start) / 16 and the offset x_j inside it.  A
-// batch of four spans goes through four phases.  (1) Per span: the entries; each fetches the 32 bytes of data lane v_j
-// (eight ds_bpermute) into the batch's gather list in LDS.  (2) ONE masked pass over the gathered vectors, 64 entries at
-// a time, leaves every entry's prefix sums pre_j (sums of the first x_j bytes) in its slot.  (3) Per span: full sums per
-// data lane, their exclusive wave scan E (u32 pieces, six v_add_u32_dpp each); entry j then knows the sums from the span's
-// start to its end, Q_j = E[v_j] + pre_j, and the read that ends there owns Q_j - Q_(j-1) -- the first of the span
-// Q_0 + S, S being the wave-uniform carry of the open read -- and lane j stores the record of read r + j: consecutive
-// lanes, consecutive records.  What lies behind the last end, total - Q_last, is the new carry.  Ends that share a
-// vector, empty reads, ends on a span's edge are all just entries; only a span with 64 or more ends (reads of fewer
-// than 16 bytes on average) goes span by span through span_scan.  The error sums are recombined to 64 bits before any
-// subtraction (the pieces of a difference are not field by field non-negative); the packed counters subtract as they are.
-//
-// ALL: a batch whose reads average fewer bytes than the density threshold is dense nearly everywhere, and tile_kernel's
-// pass over it would do nothing but probe and append (0.21 of 1.40 ms at a mean of 500 B).  Such a batch is launched as
-// dense_kernel<.., true> alone: one wave per tile of the batch, no list, the first read by the same 64-ary search.
+// span (from the window registers), the vector it cuts v_j = (p_j - span_start) / 16 and the offset x_j inside it, and
+// fetches the 32 bytes of data lane v_j (eight ds_bpermute).  The span's data lanes scan their full sums (u32 pieces,
+// six v_add_u32_dpp each); with E_j the sums in front of the entry's vector (the exclusive scan at lane v_j) and pre_j the
+// sums of the first x_j bytes of that vector, the read that ends at entry j owns
+//     own_j = B_j + pre_j - pre_(j-1),   B_j = E_j - E_(j-1)       (j - 1 in the same span)
+//                                        B_j = E_j + S              (first entry of its span; S = all whole vectors
+//                                                                    since the vector of entry j - 1, that vector included)
+// for ANY two consecutive entries of the tile: everything that needs a masked pass over cut vectors is pre_j - pre_(j-1).
+// So an entry is QUEUED: a span leaves (cut vector, x_j, B_j) in a ring in LDS and moves on; when 64 entries are waiting,
+// ONE masked pass computes their pre at full width, a shift brings pre_(j-1), and 64 consecutive lanes store 64
+// consecutive records.  (Round 2's first version finished the entries of four spans at a time: at a mean read length of
+// 500 B that is eight entries, so the masked pass and the record stores ran at an eighth of the wave's width and were a
+// third of the kernel's vector work.  Same box, that version -> this one, GB/s of the per-read kernels: mean 150 B
+// 3024 -> 3570, 250 B 3180 -> 3765, 500 B 3276 -> 3974, 1 kb 3609 -> 4416, adversarial mix 3765 -> 4132.)
+// The carry S is kept without the cut part of the newest entry's vector; it is put right (minus that entry's pre) when the
+// tile ends or a span has to go the slow way.  Ends that share a vector, empty reads, ends on a span's edge are all just
+// entries; only a span with 64 or more ends (reads of fewer than 16 bytes on average) goes through span_scan, from a
+// settled state.  The error sums are 64-bit (128-bit where the carry's high part comes in); the counters wrap in u32
+// and are exact because every true value is in range.
+constexpr int kQN = 128;   // ring slots per wave: a span adds at most 63 entries to fewer than 64 waiting ones
+
+struct PreSums { uint32_t gcs, n, qb; uint64_t err; };
+
 template <bool LINE, bool ALL>
 __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra,
-                                                       uint64_t read_base, Partial* __restrict__ head,
-                                                       Partial* __restrict__ tail, uint64_t* __restrict__ base,
-                                                       int parity) {
+                                                        uint64_t read_base, Partial* __restrict__ head,
+                                                        Partial* __restrict__ tail, uint64_t* __restrict__ base,
+                                                        int parity) {
     constexpr int ND = kDenseSpans;
     __shared__ uint64_t lut[256];
     __shared__ uint32_t xs[4][64];
-    __shared__ uint4 cutb[4][64 * ND];      // gathered cut vectors (bases); the prefix sums come back in the same slots
-    __shared__ uint4 cutq[4][64 * ND];      // (qualities)
-    __shared__ uint32_t cutx[4][64 * ND];   // their cut offsets
+    __shared__ uint4 qvb[4][kQN];      // cut vectors (bases)
+    __shared__ uint4 qvq[4][kQN];      // (qualities)
+    __shared__ uint4 qB[4][kQN];       // B: gcs, n, qb, hi >> 10
+    __shared__ uint64_t qE[4][kQN];    // B: low part of the error sum
+    __shared__ uint32_t qx[4][kQN];    // cut offset (bits 0..4), bit 8: the record is the tile's head partial
     lut[threadIdx.x] = lut_g[threadIdx.x];
     if (!ALL && blockIdx.x == 0 && threadIdx.x < kDenseSubs) base[(uint64_t)(parity ^ 1) * kDenseSubs + threadIdx.x] = 0;
     __syncthreads();
@@ -885,7 +898,6 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
     uint32_t incl = 0;
     uint64_t count = n_tiles;
     if (!ALL) {
-        // lane j: the entries of sub-list j (never more than it holds); their inclusive prefix places a global index
         const uint64_t cj = base[(uint64_t)parity * kDenseSubs + lane];
         const uint32_t mine = (uint32_t)(cj < cap ? cj : cap);
         incl = wave_scan_u32(mine);
@@ -894,19 +906,21 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
     if ((uint64_t)blockIdx.x * 4 >= count) return;   // whole block: nothing below needs a block-level barrier
     TileCtx c;
     c.read_base = read_base; c.R = b.n_reads; c.off = b.offsets; c.ra = ra; c.head = head; c.lut = lut;
-    c.lane = lane; c.lane_off = (uint32_t)lane * kVec; c.xs = &xs[wib][0]; c.line = false;   // (every line's sums are stored here)
-    uint4* __restrict__ gb = &cutb[wib][0];
-    uint4* __restrict__ gq = &cutq[wib][0];
-    uint32_t* __restrict__ gx = &cutx[wib][0];
+    c.lane = lane; c.lane_off = (uint32_t)lane * kVec; c.xs = &xs[wib][0]; c.line = false;
+    uint4* __restrict__ Qb = &qvb[wib][0];
+    uint4* __restrict__ Qq = &qvq[wib][0];
+    uint4* __restrict__ QB = &qB[wib][0];
+    uint64_t* __restrict__ QE = &qE[wib][0];
+    uint32_t* __restrict__ Qx = &qx[wib][0];
     for (uint64_t i = (uint64_t)blockIdx.x * 4 + wib; i < count; i += n_waves) {
         uint64_t e = i;
         if (!ALL) {
-            const int j = __popcll(__ballot((uint64_t)incl <= i));               // the sub-list global index i falls in
+            const int j = __popcll(__ballot((uint64_t)incl <= i));
             const uint64_t before = j ? (uint32_t)__builtin_amdgcn_readlane((int)incl, j - 1) : 0u;
             e = sload_u64(base, kDenseHeader + (uint64_t)j * cap + (i - before));
         }
         const uint64_t t = e & 0xFFFFFFFFull;
-        if (t >= n_tiles || (!ALL && (e >> 32) >= b.n_reads)) continue;   // not an entry of this batch: touch nothing
+        if (t >= n_tiles || (!ALL && (e >> 32) >= b.n_reads)) continue;
         const uint64_t tile_start = t << b.tile_shift;
         const uint64_t remain = b.n_bytes - tile_start;
         const uint32_t tile_valid = remain < kTile ? (uint32_t)remain : (uint32_t)kTile;
@@ -930,105 +944,61 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
         w.re_rel = rel_end(w.re, tile_start);
         Acc acc{0, 0, 0, 0};
         bool dirty = false;
-        Carry S{0, 0, 0, 0, 0};
+        Carry S{0, 0, 0, 0, 0};          // without the cut part of the newest entry's vector: the true carry is S - Pp
+        PreSums Pp{0, 0, 0, 0};          // pre of the newest FINISHED entry (zero in front of the tile's first one)
+        uint32_t q_head = 0, q_tail = 0; // entries finished / queued so far (ring slot = index & (kQN - 1))
+        uint64_t q_r0 = w.r;             // read of entry 0
+
+        // finish up to 64 waiting entries: the masked pass, the records
+        auto drain = [&](uint32_t m) {
+            const uint32_t slot = (q_head + ((uint32_t)lane < m ? (uint32_t)lane : 0u)) & (kQN - 1);
+            const uint32_t xf = Qx[slot];
+            const Acc pre = vec_prefix(Qb[slot], LINE ? Qb[slot] : Qq[slot], (int)(xf & 31u), c.lut);
+            uint32_t pg = (uint32_t)__shfl_up((int)pre.gcs, 1), pn = (uint32_t)__shfl_up((int)pre.n, 1);
+            uint32_t pqb = (uint32_t)__shfl_up((int)pre.qb, 1);
+            uint64_t pe = __shfl_up((unsigned long long)pre.err, 1);
+            if (lane == 0) { pg = Pp.gcs; pn = Pp.n; pqb = Pp.qb; pe = Pp.err; }   // zero in front of the tile's first entry
+            if ((uint32_t)lane < m) {
+                const uint4 B = QB[slot];
+                const uint32_t gcs = B.x + pre.gcs - pg, nn = B.y + pre.n - pn, qb = B.z + pre.qb - pqb;
+                const unsigned __int128 X = ((unsigned __int128)B.w << 42) + QE[slot] + pre.err - pe;
+                const uint64_t ri = c.read_base + q_r0 + q_head + (uint32_t)lane;
+                const bool to_head = (xf & 256u) != 0;
+                Partial* p = &c.head[c.t];
+                *(to_head ? &p->cnt : &c.ra.rec_cnt[ri]) = pack_cnt(gcs, nn, qb);
+                *(to_head ? &p->hi : &c.ra.rec_hi[ri]) = (uint64_t)(X >> 32);
+                *(to_head ? &p->lo : &c.ra.rec_lo[ri]) = (uint64_t)X & 0xffffffffull;
+            }
+            Pp.gcs = (uint32_t)__builtin_amdgcn_readlane((int)pre.gcs, (int)m - 1);
+            Pp.n = (uint32_t)__builtin_amdgcn_readlane((int)pre.n, (int)m - 1);
+            Pp.qb = (uint32_t)__builtin_amdgcn_readlane((int)pre.qb, (int)m - 1);
+            Pp.err = readlane_u64(pre.err, (int)m - 1);
+            q_head += m;
+        };
+        // everything finished and the carry put right: S becomes the true carry, the ring is empty
+        auto settle = [&]() {
+            while (q_tail != q_head) {
+                const uint32_t pend = q_tail - q_head;
+                drain(pend < 64u ? pend : 64u);
+            }
+            S.gcs -= Pp.gcs; S.n -= Pp.n; S.qb -= Pp.qb;
+            const unsigned __int128 X = ((unsigned __int128)S.hi << 32) + S.lo - Pp.err;
+            S.hi = ((uint64_t)(X >> 42)) << 10;
+            S.lo = (uint64_t)(X - ((unsigned __int128)S.hi << 32));
+            Pp = PreSums{0, 0, 0, 0};
+        };
+
         for (uint32_t s0 = 0; s0 < n_spans && !w.done; s0 += ND) {
             if (s0) load_part<0, ND, ND, true, LINE>(vb, vq, pb, pq, s0, c.lane_off, last_vec);
-            // ---- (1) the entries of the batch's spans, their vectors gathered in LDS
-            const uint64_t r0 = w.r, rs0 = w.rs, re0 = w.re;
-            uint32_t relk[ND], rdel[ND], nk[ND];
-            uint32_t nproc = 0, n_cuts = 0;
-            bool ok = true;
 #pragma unroll
             for (int k = 0; k < ND; ++k) {
-                relk[k] = 0; rdel[k] = 0; nk[k] = 0;
-                if (s0 + k >= n_spans || w.done || !ok) continue;
-                nproc = k + 1;
-                rdel[k] = (uint32_t)(w.r - r0);
-                const uint64_t span_start = tile_start + (uint64_t)(s0 + k) * kSpan, span_end = span_start + kSpan;
-                if (w.re >= span_end) continue;   // no end inside: a fast span
-                win_ensure(W, c, w.r);
-                const uint64_t ends = win_ends(W, w.r, lane);
-                // (a malformed device CSR may hold ends out of order: only the leading run of ends inside the span counts,
-                // so every index stays in range; finalize_reads reports the batch)
-                const bool in = w.r + (uint64_t)lane < c.R && ends < span_end && ends >= span_start;
-                const uint64_t nin = ~__ballot(in);
-                const uint32_t n = nin ? (uint32_t)__builtin_ctzll(nin) : 64u;
-                if (n == 0 || n >= 64) { ok = false; continue; }   // 64 ends in one span: span by span (below)
-                const uint32_t rel = (uint32_t)(ends - span_start) & (kSpan - 1);
-                const int v = (int)(rel >> 4);
-                const uint4 eb = make_uint4((uint32_t)__shfl((int)vb[k].x, v), (uint32_t)__shfl((int)vb[k].y, v),
-                                            (uint32_t)__shfl((int)vb[k].z, v), (uint32_t)__shfl((int)vb[k].w, v));
-                uint4 eq = eb;
-                if (!LINE)
-                    eq = make_uint4((uint32_t)__shfl((int)vq[k].x, v), (uint32_t)__shfl((int)vq[k].y, v),
-                                    (uint32_t)__shfl((int)vq[k].z, v), (uint32_t)__shfl((int)vq[k].w, v));
-                if ((uint32_t)lane < n) {
-                    gb[n_cuts + lane] = eb;
-                    gq[n_cuts + lane] = eq;
-                    gx[n_cuts + lane] = rel & 15u;
-                }
-                relk[k] = rel;
-                nk[k] = n;
-                n_cuts += n;
-                w.rs = readlane_u64(ends, (int)n - 1);
-                w.r += n;
-                w.done = w.r >= c.R;
-                if (!w.done) {
-                    w.re = readlane_u64(ends, (int)n);   // n < 64: the end of read w.r is in the same register
-                    w.re_rel = rel_end(w.re, tile_start);
-                }
-            }
-            if (!ok) {
-                // a span with 64 or more ends somewhere in the batch: span by span, from the state the batch began with
-                w.r = r0; w.rs = rs0; w.re = re0; w.done = false;
-                w.re_rel = rel_end(w.re, tile_start);
-                w.win_ok = false;
-#pragma unroll
-                for (int k = 0; k < ND; ++k) {
-                    if (s0 + k >= n_spans || w.done) break;
-                    const uint32_t span_rel = (s0 + k) * kSpan, span_end_rel = span_rel + kSpan;
-                    if (w.re_rel <= span_rel && span_rel != 0) {
-                        // (an end left on this span's edge by the batch before: the read owns nothing here)
-                        flush_read_c(acc, dirty, S, w, c);
-                        walk_advance<true>(w, c);
-                        if (w.done) break;
-                    }
-                    if (w.re_rel >= span_end_rel) {
-                        Acc tot = vec_sums(vb[k], LINE ? vb[k] : vq[k], c.lut);
-                        acc_add(acc, tot);
-                        dirty = true;
-                        if (w.re_rel == span_end_rel) {
-                            flush_read_c(acc, dirty, S, w, c);
-                            walk_advance<true>(w, c);
-                        }
-                    } else {
-                        span_scan(vb[k], LINE ? vb[k] : vq[k], span_rel, w, acc, dirty, S, c);
-                    }
-                }
-                W.ok = false;
-                continue;
-            }
-            __builtin_amdgcn_wave_barrier();
-            // ---- (2) one masked pass over the gathered vectors (64 at a time): slot = {gcs | n << 16, qb, err}
-            for (uint32_t g0 = 0; g0 < n_cuts; g0 += 64) {
-                const uint32_t gi = g0 + (uint32_t)lane < n_cuts ? g0 + (uint32_t)lane : n_cuts - 1;
-                const Acc pre = vec_prefix(gb[gi], gq[gi], (int)gx[gi], c.lut);
-                __builtin_amdgcn_wave_barrier();
-                if (g0 + (uint32_t)lane < n_cuts)
-                    gb[gi] = make_uint4(pre.gcs | (pre.n << 16), pre.qb, (uint32_t)pre.err, (uint32_t)(pre.err >> 32));
-            }
-            __builtin_amdgcn_wave_barrier();
-            // ---- (3) per span: full sums, exclusive scan, the entries' records
-            uint32_t cbase = 0;
-            bool head_pending = rs0 < tile_start;   // the open read began in an earlier tile: its end is the head partial
-#pragma unroll
-            for (int k = 0; k < ND; ++k) {
-                if ((uint32_t)k >= nproc) break;
-                const uint32_t n = nk[k];
-                if (!n) {
+                if (s0 + k >= n_spans || w.done) break;
+                const uint32_t span_rel = (s0 + k) * kSpan, span_end_rel = span_rel + kSpan;
+                const uint64_t span_start = tile_start + span_rel, span_end = span_start + kSpan;
+                if (w.re >= span_end) {   // no end inside: a fast span
                     Acc tot;
                     if (LINE) {
-                        const uint32_t ty = (uint32_t)(r0 + rdel[k]) & 3u;
+                        const uint32_t ty = (uint32_t)w.r & 3u;
                         if (ty == 1u) tot = vec_sums_bases(vb[k]);
                         else if (ty == 3u) tot = vec_sums_quals(vb[k], c.lut);
                         else tot = Acc{0, 0, 0, 0};
@@ -1039,6 +1009,47 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
                     dirty = true;
                     continue;
                 }
+                win_ensure(W, c, w.r);
+                const uint64_t ends = win_ends(W, w.r, lane);
+                const bool in = w.r + (uint64_t)lane < c.R && ends < span_end && ends >= span_start;
+                const uint64_t nin = ~__ballot(in);
+                const uint32_t n = nin ? (uint32_t)__builtin_ctzll(nin) : 64u;
+                if (n == 0 || n >= 64) {
+                    // 64 ends or more in one span (or a malformed index): the span goes through span_scan, from a settled state
+                    settle();
+                    w.re_rel = rel_end(w.re, tile_start);
+                    w.win_ok = false;
+                    if (w.re_rel <= span_rel && span_rel != 0) {
+                        flush_read_c(acc, dirty, S, w, c);
+                        walk_advance<true>(w, c);
+                    }
+                    if (!w.done) {
+                        if (w.re_rel >= span_end_rel) {
+                            const Acc tot = vec_sums(vb[k], LINE ? vb[k] : vq[k], c.lut);
+                            acc_add(acc, tot);
+                            dirty = true;
+                            if (w.re_rel == span_end_rel) {
+                                flush_read_c(acc, dirty, S, w, c);
+                                walk_advance<true>(w, c);
+                            }
+                        } else {
+                            span_scan(vb[k], LINE ? vb[k] : vq[k], span_rel, w, acc, dirty, S, c);
+                        }
+                    }
+                    W.ok = false;
+                    q_head = q_tail = 0;
+                    q_r0 = w.r;
+                    continue;
+                }
+                // ---- the entries of this span: their vectors into the ring
+                const uint32_t rel = (uint32_t)(ends - span_start) & (kSpan - 1);
+                const int v = (int)(rel >> 4);
+                const uint4 eb = make_uint4((uint32_t)__shfl((int)vb[k].x, v), (uint32_t)__shfl((int)vb[k].y, v),
+                                            (uint32_t)__shfl((int)vb[k].z, v), (uint32_t)__shfl((int)vb[k].w, v));
+                uint4 eq = eb;
+                if (!LINE)
+                    eq = make_uint4((uint32_t)__shfl((int)vq[k].x, v), (uint32_t)__shfl((int)vq[k].y, v),
+                                    (uint32_t)__shfl((int)vq[k].z, v), (uint32_t)__shfl((int)vq[k].w, v));
                 const Acc tot = vec_sums(vb[k], LINE ? vb[k] : vq[k], c.lut);
                 if (dirty) {   // fast spans since the last end: fold the per-lane sums into the carry
                     Carry Z = S;
@@ -1057,40 +1068,55 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
                 const Pieces a = to_pieces(tot);
                 const Pieces P{wave_scan_u32(a.c1), wave_scan_u32(a.c2), wave_scan_u32(a.e0), wave_scan_u32(a.e1)};
                 const uint32_t Ec1 = P.c1 - a.c1, Eqb = (P.c2 - a.c2) & 0x3FFFFu;
-                const uint64_t Eerr = pieces_err(P) - tot.err;
+                const uint64_t Perr = pieces_err(P);
+                const uint64_t Eerr = Perr - tot.err;
                 const uint32_t Tc1 = (uint32_t)__builtin_amdgcn_readlane((int)P.c1, 63);
                 const uint32_t Tqb = (uint32_t)__builtin_amdgcn_readlane((int)P.c2, 63) & 0x3FFFFu;
-                const uint64_t Terr = readlane_u64(pieces_err(P), 63);
-                // entry lanes: sums from the span's start to the entry's end
-                const int v = (int)(relk[k] >> 4);
-                const uint4 pv = gb[cbase + ((uint32_t)lane < n ? (uint32_t)lane : 0u)];
-                cbase += n;
-                const uint32_t Qc1 = (uint32_t)__shfl((int)Ec1, v) + pv.x;
-                const uint32_t Qqb = (uint32_t)__shfl((int)Eqb, v) + pv.y;
-                const uint64_t Qerr = __shfl((unsigned long long)Eerr, v) + ((uint64_t)pv.z | ((uint64_t)pv.w << 32));
-                const uint32_t pc1 = (uint32_t)__shfl_up((int)Qc1, 1), pqb = (uint32_t)__shfl_up((int)Qqb, 1);
-                const uint64_t perr = __shfl_up((unsigned long long)Qerr, 1);
+                const uint64_t Terr = readlane_u64(Perr, 63);
+                // entry lanes: what lies in front of the entry's vector, then B
+                const uint32_t Jc1 = (uint32_t)__shfl((int)Ec1, v), Jqb = (uint32_t)__shfl((int)Eqb, v);
+                const uint64_t Jerr = __shfl((unsigned long long)Eerr, v);
+                const uint32_t pc1 = (uint32_t)__shfl_up((int)Jc1, 1), pqb = (uint32_t)__shfl_up((int)Jqb, 1);
+                const uint64_t perr = __shfl_up((unsigned long long)Jerr, 1);
                 if ((uint32_t)lane < n) {
                     const bool first = lane == 0;
-                    const uint32_t oc1 = Qc1 - (first ? 0u : pc1);
-                    uint32_t gcs = oc1 & 0xFFFFu, nn = oc1 >> 16, qb = Qqb - (first ? 0u : pqb);
-                    uint64_t lo = Qerr - (first ? 0ull : perr), hi = 0;
-                    if (first) { gcs += S.gcs; nn += S.n; qb += S.qb; lo += S.lo; hi = S.hi; }
-                    const uint64_t ri = c.read_base + r0 + rdel[k] + (uint32_t)lane;
-                    const bool to_head = first && head_pending;
-                    Partial* p = &c.head[c.t];
-                    *(to_head ? &p->cnt : &c.ra.rec_cnt[ri]) = pack_cnt(gcs, nn, qb);
-                    *(to_head ? &p->hi : &c.ra.rec_hi[ri]) = hi;
-                    *(to_head ? &p->lo : &c.ra.rec_lo[ri]) = lo;
+                    const uint32_t dc1 = Jc1 - (first ? 0u : pc1);   // both fields of an exclusive prefix only grow
+                    uint4 B = make_uint4(dc1 & 0xFFFFu, dc1 >> 16, Jqb - (first ? 0u : pqb), 0u);
+                    uint64_t be = Jerr - (first ? 0ull : perr);
+                    uint32_t flag = 0;
+                    if (first) {
+                        B.x += S.gcs; B.y += S.n; B.z += S.qb; B.w = (uint32_t)(S.hi >> 10);
+                        be += S.lo;
+                        flag = w.rs < tile_start ? 256u : 0u;   // the open read began in an earlier tile: the head partial
+                    }
+                    const uint32_t slot = (q_tail + (uint32_t)lane) & (kQN - 1);
+                    Qb[slot] = eb;
+                    if (!LINE) Qq[slot] = eq;
+                    QB[slot] = B;
+                    QE[slot] = be;
+                    Qx[slot] = (rel & 15u) | flag;
                 }
-                // what lies behind the last end opens the next read
-                const uint32_t Lc1 = Tc1 - (uint32_t)__builtin_amdgcn_readlane((int)Qc1, (int)n - 1);
-                const uint32_t Lqb = Tqb - (uint32_t)__builtin_amdgcn_readlane((int)Qqb, (int)n - 1);
-                const uint64_t Lerr = Terr - readlane_u64(Qerr, (int)n - 1);
-                S = Carry{Lc1 & 0xFFFFu, Lc1 >> 16, Lqb, 0, Lerr};
-                head_pending = false;
+                // the whole vectors from the last entry's on open the next read
+                {
+                    const int last = (int)n - 1;
+                    const uint32_t Lc1 = Tc1 - (uint32_t)__builtin_amdgcn_readlane((int)Jc1, last);
+                    const uint32_t Lqb = Tqb - (uint32_t)__builtin_amdgcn_readlane((int)Jqb, last);
+                    const uint64_t Lerr = Terr - readlane_u64(Jerr, last);
+                    S = Carry{Lc1 & 0xFFFFu, Lc1 >> 16, Lqb, 0, Lerr};
+                }
+                q_tail += n;
+                w.rs = readlane_u64(ends, (int)n - 1);
+                w.r += n;
+                w.done = w.r >= c.R;
+                if (!w.done) {
+                    w.re = readlane_u64(ends, (int)n);   // n < 64: the end of read w.r is in the same register
+                    w.re_rel = rel_end(w.re, tile_start);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (q_tail - q_head >= 64u) drain(64u);
             }
         }
+        settle();
         if (!w.done) {
             if (w.re == tile_start + tile_valid) {
                 flush_read_c(acc, dirty, S, w, c);     // the read ends with the tile: complete, or the head partial
@@ -1191,13 +1217,13 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
 }
 
 constexpr uint32_t kDenseLen = 768;    // a tile is dense when its reads average fewer bytes than this
-// dense_kernel alone (no tile_kernel pass, no list) for a batch whose reads average fewer than kDenseAllLen bytes: at a
-// mean of 1 kb it is as fast as the pair (3870 against 3840 GB/s), below that faster (mean 500 B: 3525 against 3070, 150 B:
-// 3330 against 3030), above it slower (2.5 kb: 4540 against 5630: its sparse spans run at 3 waves per SIMD with 8 loads
-// in flight).  A small batch pays the pair's second launch and the wait between the two (about 15 us) whatever it holds,
-// which is what dense_kernel loses on 190 MB of sparse tiles: below kSmallBatchBytes the bound is kDenseAllLenSmall
-// (the adversarial mix of BASELINE config 4, 240 MB, mean 1.2 kb: 0.126 against 0.141 ms).
-constexpr uint32_t kDenseAllLen = 1024, kDenseAllLenSmall = 2048;
+// dense_kernel alone (no tile_kernel pass, no list) for a batch whose reads average fewer than kDenseAllLen bytes.  Same
+// box, alone against the pair (GB/s): mean 1 kb 4458 / 3652, 1.5 kb 4675 / 4438, 2 kb 4706 / 4890, 2.5 kb 4886 / 5457,
+// 4 kb 5248 / 5910 (its sparse spans run at 3 waves per SIMD with 8 loads in flight).  The per-tile threshold of the pair
+// stays at 768 B (1280, 1792 and 2560 are slower at every mean tried).  A small batch pays the pair's second launch and the
+// wait between the two (about 15 us) whatever it holds: below kSmallBatchBytes the bound is kDenseAllLenSmall (the
+// adversarial mix of BASELINE config 4, 240 MB, mean 1.2 kb: 0.119 against 0.131 ms).
+constexpr uint32_t kDenseAllLen = 1792, kDenseAllLenSmall = 2560;
 constexpr uint64_t kSmallBatchBytes = 256ull << 20;
 
 template <int NB, bool NT, bool PIPE, bool LINE = false, bool VECB = false>

@@ -43,12 +43,13 @@ for rnd in range(rounds + 1):
             os.environ.pop("PPQC_TILE_DENSE", None); os.environ.pop("PPQC_TILE_DENSE_LEN", None)
             os.environ.pop("PPQC_TILE_ALL", None)
             vv = v
-            if v[0] == "0":
+            if v[0] == "0":      # "0<flags>[:LEN]"
                 vv = "0"
-                if v.endswith("d"): os.environ["PPQC_TILE_DENSE"] = "1"
-                if v.endswith("s"): os.environ["PPQC_TILE_DENSE"] = "0"
-                if v.endswith("a"): os.environ["PPQC_TILE_ALL"] = "1"    # dense_kernel alone over every tile
-                if v.endswith("p"): os.environ["PPQC_TILE_ALL"] = "0"    # always the pair, whatever the mean
+                flags = v.split(":")[0][1:]
+                if "d" in flags: os.environ["PPQC_TILE_DENSE"] = "1"     # every tile onto the dense list
+                if "s" in flags: os.environ["PPQC_TILE_DENSE"] = "0"     # every tile sparse (tile_kernel alone)
+                if "a" in flags: os.environ["PPQC_TILE_ALL"] = "1"       # the dense kernel alone over every tile
+                if "p" in flags: os.environ["PPQC_TILE_ALL"] = "0"       # always the pair, whatever the mean
                 if ":" in v: os.environ["PPQC_TILE_DENSE_LEN"] = v.split(":")[1]
             os.environ["PPQC_TILE_VARIANT"] = vv
             os.environ["PPQC_TILE_BLOCKS_PER_CU"] = bpc
