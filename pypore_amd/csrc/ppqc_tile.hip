@@ -886,8 +886,6 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
     __shared__ uint4 qB[4][kQN];       // B: gcs, n, qb, hi >> 10
     __shared__ uint64_t qE[4][kQN];    // B: low part of the error sum
     __shared__ uint32_t qx[4][kQN];    // cut offset (bits 0..4), bit 8: the record is the tile's head partial
-    const bool roll = !(parity & 2);   // (bit 1 of the argument: A/B knob, see the span loop)
-    parity &= 1;
     lut[threadIdx.x] = lut_g[threadIdx.x];
     if (!ALL && blockIdx.x == 0 && threadIdx.x < kDenseSubs) base[(uint64_t)(parity ^ 1) * kDenseSubs + threadIdx.x] = 0;
     __syncthreads();
@@ -990,36 +988,22 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
             Pp = PreSums{0, 0, 0, 0};
         };
 
-        // Rolling refill: when span s0 + k is done with its registers, span s0 + ND + k is requested into them, so eight
-        // loads stay in flight per lane all the time (a wave here has a third of tile_kernel's loads in flight per SIMD).
-        // `roll` = 0 (PPQC_DENSE_ROLL=0, A/B): the next four spans are requested when the batch is over.
         for (uint32_t s0 = 0; s0 < n_spans && !w.done; s0 += ND) {
-            if (s0 && !roll) load_part<0, ND, ND, true, LINE>(vb, vq, pb, pq, s0, c.lane_off, last_vec);
+            if (s0) load_part<0, ND, ND, true, LINE>(vb, vq, pb, pq, s0, c.lane_off, last_vec);
 #pragma unroll
             for (int k = 0; k < ND; ++k) {
                 if (s0 + k >= n_spans || w.done) break;
-                const uint4 cb = vb[k], cq = LINE ? vb[k] : vq[k];   // this span's data; its registers are free from here on
-                if (roll && s0 + ND + k < n_spans) {
-                    uint32_t o = (s0 + ND + k) * kSpan + c.lane_off;
-                    o = o < last_vec ? o : last_vec;
-                    const u32x4 tb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pb + o));
-                    vb[k] = make_uint4(tb[0], tb[1], tb[2], tb[3]);
-                    if (!LINE) {
-                        const u32x4 tq = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pq + o));
-                        vq[k] = make_uint4(tq[0], tq[1], tq[2], tq[3]);
-                    }
-                }
                 const uint32_t span_rel = (s0 + k) * kSpan, span_end_rel = span_rel + kSpan;
                 const uint64_t span_start = tile_start + span_rel, span_end = span_start + kSpan;
                 if (w.re >= span_end) {   // no end inside: a fast span
                     Acc tot;
                     if (LINE) {
                         const uint32_t ty = (uint32_t)w.r & 3u;
-                        if (ty == 1u) tot = vec_sums_bases(cb);
-                        else if (ty == 3u) tot = vec_sums_quals(cb, c.lut);
+                        if (ty == 1u) tot = vec_sums_bases(vb[k]);
+                        else if (ty == 3u) tot = vec_sums_quals(vb[k], c.lut);
                         else tot = Acc{0, 0, 0, 0};
                     } else {
-                        tot = vec_sums(cb, cq, c.lut);
+                        tot = vec_sums(vb[k], vq[k], c.lut);
                     }
                     acc_add(acc, tot);
                     dirty = true;
@@ -1041,7 +1025,7 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
                     }
                     if (!w.done) {
                         if (w.re_rel >= span_end_rel) {
-                            const Acc tot = vec_sums(cb, cq, c.lut);
+                            const Acc tot = vec_sums(vb[k], LINE ? vb[k] : vq[k], c.lut);
                             acc_add(acc, tot);
                             dirty = true;
                             if (w.re_rel == span_end_rel) {
@@ -1049,7 +1033,7 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
                                 walk_advance<true>(w, c);
                             }
                         } else {
-                            span_scan(cb, cq, span_rel, w, acc, dirty, S, c);
+                            span_scan(vb[k], LINE ? vb[k] : vq[k], span_rel, w, acc, dirty, S, c);
                         }
                     }
                     W.ok = false;
@@ -1060,13 +1044,13 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
                 // ---- the entries of this span: their vectors into the ring
                 const uint32_t rel = (uint32_t)(ends - span_start) & (kSpan - 1);
                 const int v = (int)(rel >> 4);
-                const uint4 eb = make_uint4((uint32_t)__shfl((int)cb.x, v), (uint32_t)__shfl((int)cb.y, v),
-                                            (uint32_t)__shfl((int)cb.z, v), (uint32_t)__shfl((int)cb.w, v));
+                const uint4 eb = make_uint4((uint32_t)__shfl((int)vb[k].x, v), (uint32_t)__shfl((int)vb[k].y, v),
+                                            (uint32_t)__shfl((int)vb[k].z, v), (uint32_t)__shfl((int)vb[k].w, v));
                 uint4 eq = eb;
                 if (!LINE)
-                    eq = make_uint4((uint32_t)__shfl((int)cq.x, v), (uint32_t)__shfl((int)cq.y, v),
-                                    (uint32_t)__shfl((int)cq.z, v), (uint32_t)__shfl((int)cq.w, v));
-                const Acc tot = vec_sums(cb, cq, c.lut);
+                    eq = make_uint4((uint32_t)__shfl((int)vq[k].x, v), (uint32_t)__shfl((int)vq[k].y, v),
+                                    (uint32_t)__shfl((int)vq[k].z, v), (uint32_t)__shfl((int)vq[k].w, v));
+                const Acc tot = vec_sums(vb[k], LINE ? vb[k] : vq[k], c.lut);
                 if (dirty) {   // fast spans since the last end: fold the per-lane sums into the carry
                     Carry Z = S;
                     const uint32_t G = wave_sum_u32(acc.gcs), N = wave_sum_u32(acc.n), Q = wave_sum_u32(acc.qb);
@@ -1288,8 +1272,6 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
     DenseOut dz = make_dense_out(dl.base, dl.parity, mode, T);
     hipError_t e;
     // a batch that is dense on average: dense_kernel alone, over every tile (PPQC_TILE_ALL = 0 | 1 overrides the choice)
-    const char* dr = getenv("PPQC_DENSE_ROLL");
-    const int noroll = (dr && atoi(dr) == 0) ? 2 : 0;
     const char* da = getenv("PPQC_TILE_ALL");
     const bool all = da ? atoi(da) != 0
                         : (mode == 0 && b.n_bytes / b.n_reads < (b.n_bytes < kSmallBatchBytes ? kDenseAllLenSmall : kDenseAllLen));
@@ -1299,10 +1281,10 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
         if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
         if (line_mode)
             hipLaunchKernelGGL((dense_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base,
-                               head, tail, dl.base, dl.parity | noroll);
+                               head, tail, dl.base, dl.parity);
         else
             hipLaunchKernelGGL((dense_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base,
-                               head, tail, dl.base, dl.parity | noroll);
+                               head, tail, dl.base, dl.parity);
         return hipGetLastError();
     }
     if (line_mode) {
@@ -1335,10 +1317,10 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
     if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
     if (line_mode)
         hipLaunchKernelGGL((dense_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head, tail,
-                           dl.base, dl.parity | noroll);
+                           dl.base, dl.parity);
     else
         hipLaunchKernelGGL((dense_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head,
-                           tail, dl.base, dl.parity | noroll);
+                           tail, dl.base, dl.parity);
     e = hipGetLastError();
     // the counters change roles only when a dense_kernel has run: it is what leaves the other counter at zero
     if (e == hipSuccess) dl.parity ^= 1;

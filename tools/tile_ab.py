@@ -41,14 +41,13 @@ for rnd in range(rounds + 1):
             # "0" = the shipped pair of kernels (per-tile probe); "0s" / "0d" force every tile sparse / dense;
             # "0a" / "0p": dense_kernel alone / always the pair; "0:LEN" sets the density threshold; "108" = the older one-kernel VECB instantiation
             os.environ.pop("PPQC_TILE_DENSE", None); os.environ.pop("PPQC_TILE_DENSE_LEN", None)
-            os.environ.pop("PPQC_TILE_ALL", None); os.environ.pop("PPQC_DENSE_ROLL", None)
+            os.environ.pop("PPQC_TILE_ALL", None)
             vv = v
             if v[0] == "0":      # "0<flags>[:LEN]"
                 vv = "0"
                 flags = v.split(":")[0][1:]
                 if "d" in flags: os.environ["PPQC_TILE_DENSE"] = "1"     # every tile onto the dense list
                 if "s" in flags: os.environ["PPQC_TILE_DENSE"] = "0"     # every tile sparse (tile_kernel alone)
-                if "r" in flags: os.environ["PPQC_DENSE_ROLL"] = "0"     # dense kernel: next spans requested per batch, not rolling
                 if "a" in flags: os.environ["PPQC_TILE_ALL"] = "1"       # the dense kernel alone over every tile
                 if "p" in flags: os.environ["PPQC_TILE_ALL"] = "0"       # always the pair, whatever the mean
                 if ":" in v: os.environ["PPQC_TILE_DENSE_LEN"] = v.split(":")[1]
