@@ -61,6 +61,7 @@ def parse(argv=None):
                     help="wall clock of `pypore seqstats` (albacore FASTQ mode) over a synthetic FASTQ directory on tmpfs, "
                          "beside the reference-shaped Python on the same files (not the headline metric)")
     ap.add_argument("--cli-gbases", type=float, default=2.0)
+    ap.add_argument("--cli-threads", type=int, default=4, help="--cli: the command's -n (loader threads)")
     ap.add_argument("--dist-path", action="store_true",
                     help="with one GPU: run the step through the multi-GPU merge path (1-rank RCCL group) to time it")
     ap.add_argument("--launcher-selftest", action="store_true",
@@ -446,7 +447,7 @@ def cli_mode(a):
         env = dict(os.environ)
         env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
         cmd = [sys.executable, "-m", "pypore_amd.pypore", "seqstats", "-i", os.path.join(work, "in"), "-l", "bench", "-f",
-               "fastq", "-o", "out", "-v", "0"] + (["--gpus", str(a.gpus)] if a.gpus > 1 else [])
+               "fastq", "-o", "out", "-v", "0", "-n", str(a.cli_threads)] + (["--gpus", str(a.gpus)] if a.gpus > 1 else [])
         walls = []
         for _ in range(max(1, a.steps if a.steps < 4 else 3)):
             t0 = time.perf_counter()
@@ -464,11 +465,13 @@ def cli_mode(a):
                "wall_seconds_all_runs": [round(w, 3) for w in walls], "file_GBps": round(text_bytes / wall / 1e9, 3),
                "data": "synthetic", "dtype": "u8",
                "config": {"workload": "%d reads, %.2f Gbases, %.2f GB of FASTQ text in %d files of %d records under %s; "
-                                      "summary + pore-activity HTML written" % (R, nb / 1e9, text_bytes / 1e9, n_files,
-                                                                                 a.batch_reads, base)},
+                                      "-n %d; summary + pore-activity HTML written" % (R, nb / 1e9, text_bytes / 1e9,
+                                                                                        n_files, a.batch_reads, base,
+                                                                                        a.cli_threads)},
                "reference_shaped_cpu": ref_res}
         if os.environ.get("PPQC_CLI_BREAKDOWN"):     # where the wall clock goes (tools/cli_breakdown.py), same files
-            subprocess.call([sys.executable, os.path.join(ROOT, "tools", "cli_breakdown.py"), os.path.join(work, "in")],
+            subprocess.call([sys.executable, os.path.join(ROOT, "tools", "cli_breakdown.py"), os.path.join(work, "in"),
+                             str(a.cli_threads)],
                             cwd=work, env=env)
         print(json.dumps(out), flush=True)
     finally:

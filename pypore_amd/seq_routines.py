@@ -573,9 +573,13 @@ def summary_channel_dict(rows, dev=None):
     return channel_dict_from_tables(tables, summary=True)
 
 
-def _submit_fastq_files(ctx, files, host_meta, keep=None):
-    """Every file through the GPU tokenizer (ppqc_submit_fastq): a loader thread reads each file straight into a pinned
-    host slot while the previous one is copied and reduced (staging.Stage), the text goes to the card as it is.  A text
+MAX_LOADERS = 8     # loader threads that read files into pinned slots (-n asks, this caps: each holds a file's text pinned)
+
+
+def _submit_fastq_files(ctx, files, host_meta, keep=None, threads=1):
+    """Every file through the GPU tokenizer (ppqc_submit_fastq): ``threads`` loader threads (the CLI's -n, at most
+    MAX_LOADERS) read files straight into pinned host slots while earlier ones are copied and reduced (staging.Stage:
+    the files are submitted in their order whoever read them), the text goes to the card as it is.  A text
     the strict tokenizer refuses (blank lines between records, which SeqIO tolerates) goes through the host packer
     instead, with ``host_meta(packed, path)`` supplying (channel, mux, time).  ``keep``: a list that receives
     (path, packed) of every file, host-packed, for -fq (then every file takes the host packer)."""
@@ -608,19 +612,20 @@ def _submit_fastq_files(ctx, files, host_meta, keep=None):
         ctx.slot_wait(d)                       # these arrays are pageable and die with `p`
         return False
 
-    with Stage(ctx) as stage:
+    with Stage(ctx, threads=min(max(1, int(threads or 1)), MAX_LOADERS)) as stage:
         stage.run(files, fill, submit)
     e = ctx.input_errors()
     if e["bad_quality_bytes"]:
         raise ValueError("%d quality characters outside '!'..'~' (SeqIO raises ValueError)" % e["bad_quality_bytes"])
 
 
-def fastq_gc(files, dev=None):
+def fastq_gc(files, dev=None, threads=1):
     """``fastq_reader`` over a list of FASTQ files (:40-53): per-record (gc_count, length) from the GPU, or -- several
     GPUs, every rank holding a share of the files -- the merged 20-bin GC histogram (same bins, counted on the device)."""
     with qc.QCContext(device=device if dev is None else dev, n_channels=n_channels, n_mux=1, n_time_bins=n_hours) as ctx:
         _submit_fastq_files(ctx, my_share(files), lambda p, path: (p["channel"], np.ones(p["n_reads"], np.uint8),
-                                                                   np.zeros(p["n_reads"], np.int64)))
+                                                                   np.zeros(p["n_reads"], np.int64)),
+                            threads=threads)
         if DIST is not None:
             extra = finalize_run(ctx)
             gc_table = GCCounts(int(x) for x in extra["gc_hist"])
@@ -639,7 +644,7 @@ def summary_module(fqfolder, summary_table_file, size):
     files = list(fastq_io.fastq_files(fqfolder))
     rows = summary_reader(summary_table_file)
     ChannelOut = summary_channel_dict(rows)
-    gc_table, seq_tables = fastq_gc(files)
+    gc_table, seq_tables = fastq_gc(files, threads=size)
     ChannelOut.seq_tables = seq_tables     # bonus: N50 / N count / quality from the sequences themselves
     if not is_writer():
         return ChannelOut, None, None
@@ -666,7 +671,7 @@ def fastq_module(fqfolder, Fast_flag, size):
                       time_mode=1, tz_offset_s=0, ref_time_s=0, fail_q=7.0) as ctx:
         def meta(p, path):
             return p["channel"], np.ones(p["n_reads"], np.uint8), p["start_time"]   # no mux in FASTQ headers: mux 1
-        _submit_fastq_files(ctx, my_share(files), meta, keep=packed)
+        _submit_fastq_files(ctx, my_share(files), meta, keep=packed, threads=size)
         t_submitted = time.perf_counter()
         per_read = ctx.read_stats() if Fast_flag else None
         ctx.finalize_extremes()

@@ -5,8 +5,8 @@ The reference's loaders hand every read to a worker as Python strings (lib/fast5
 lib/multi_read_fast5_reader.py:121-147, lib/seq_routines.py:896-901) and its pool pulls the next task while earlier
 results are merged (:916-942).  Here a loader thread writes each batch STRAIGHT into page-locked host memory
 (``ppqc_alloc_pinned``), as the CSR arrays ``ppqc_submit`` takes or as FASTQ text for ``ppqc_submit_fastq``, while the main
-thread hands the previous batch to the library: three host slots over the library's two device staging slots, so that one
-slot is being filled, one is being copied and one has its kernels running.  A host slot goes back to the loader when
+thread hands the previous batch to the library: one host slot per loader thread plus two, over the library's two device
+staging slots, so that slots are being filled while one is being copied and one has its kernels running.  A host slot goes back to the loader when
 ``ppqc_slot_wait`` says its copies are done.  No statistics are computed here."""
 from __future__ import annotations
 
@@ -113,55 +113,83 @@ def pack_records(recs, slot=None):
 
 
 class Stage:
-    """Loader thread + pinned host slots.  ``fill(job, slot)`` runs on the loader thread and returns the item to submit
-    (or None to skip the job); ``submit(item, device_slot)`` runs on the caller's thread and must hand the item to
-    ``ctx.submit`` / ``ctx.submit_fastq`` with that staging slot (or not touch the GPU at all)."""
+    """Loader threads + pinned host slots.  ``fill(job, slot)`` runs on a loader thread and returns the item to submit
+    (or None to skip the job); ``submit(item, device_slot)`` runs on the caller's thread, in the order of the jobs, and
+    must hand the item to ``ctx.submit`` / ``ctx.submit_fastq`` with that staging slot (or return False if it did not use
+    the GPU slot).  ``threads`` loaders fill slots side by side (reading a file into page-locked memory and inflating a
+    .gz release the GIL): two more host slots than loaders, so that one batch can be in the copy engine and one under
+    the kernels while every loader fills."""
 
-    N_HOST_SLOTS = 3
-
-    def __init__(self, ctx):
+    def __init__(self, ctx, threads=1):
         self.ctx = ctx
-        self.slots = [PinnedSlot() for _ in range(self.N_HOST_SLOTS)]
+        self.threads = max(1, int(threads))
+        self.slots = [PinnedSlot() for _ in range(self.threads + 2)]
 
     def run(self, jobs, fill, submit):
         free, ready = queue.Queue(), queue.Queue()
         for k in range(len(self.slots)):
             free.put(k)
         stop = threading.Event()
+        take = threading.Lock()
+        it = iter(jobs)
+        state = {"next": 0, "live": self.threads}
 
         def loader():
             try:
-                for job in jobs:
-                    k = free.get()
-                    if stop.is_set():
-                        return
+                while True:
+                    # a free slot FIRST, then the next job, both under one lock: the earlier job always has its slot, so
+                    # the caller, who takes the items in order, never waits for a job whose loader waits for a slot
+                    with take:
+                        k = free.get()
+                        if stop.is_set():
+                            free.put(k)
+                            return
+                        try:
+                            job = next(it)
+                        except StopIteration:
+                            free.put(k)
+                            break
+                        seq = state["next"]
+                        state["next"] += 1
                     item = fill(job, self.slots[k])
-                    if item is None:
-                        free.put(k)
-                        continue
-                    ready.put((k, item))
-                ready.put(None)
+                    ready.put((seq, k, item))
+                with take:
+                    state["live"] -= 1
+                    if state["live"] == 0:
+                        ready.put(None)
             except BaseException as e:      # handed to the caller's thread
                 ready.put(e)
 
-        th = threading.Thread(target=loader, name="ppqc-loader", daemon=True)
-        th.start()
-        in_flight, n = [], 0
+        ths = [threading.Thread(target=loader, name="ppqc-loader-%d" % i, daemon=True) for i in range(self.threads)]
+        for th in ths:
+            th.start()
+        in_flight, n, want, early = [], 0, 0, {}
         try:
-            while True:
-                got = ready.get()
-                if got is None:
-                    break
-                if isinstance(got, BaseException):
-                    raise got
-                k, item = got
-                d = n % 2
-                used = submit(item, d)
-                n += 1
-                if used is False:           # the submit did not use the GPU slot: the host slot is free at once
-                    n -= 1
+            done = False
+            while not done or early:
+                if want in early:
+                    k, item = early.pop(want)
+                else:
+                    got = ready.get()
+                    if got is None:
+                        done = True
+                        continue
+                    if isinstance(got, BaseException):
+                        raise got
+                    seq, k, item = got
+                    if seq != want:
+                        early[seq] = (k, item)
+                        continue
+                want += 1
+                if item is None:            # the job yielded nothing
                     free.put(k)
                     continue
+                d = n % 2
+                used = submit(item, d)
+                if used is False:           # the submit did not use the GPU slot: the host slot is free at once
+                    free.put(k)
+                    continue
+                n += 1
                 in_flight.append((k, d))
                 if len(in_flight) >= 2:     # the older batch's copies: done, or about to be (its slot is the other one)
                     k0, d0 = in_flight.pop(0)
@@ -169,8 +197,10 @@ class Stage:
                     free.put(k0)
         finally:
             stop.set()
-            free.put(0)                     # wakes a loader that waits for a slot
-            th.join()
+            for _ in ths:
+                free.put(0)                 # wakes loaders that wait for a slot
+            for th in ths:
+                th.join()
         for _k, d in in_flight:
             self.ctx.slot_wait(d)
 

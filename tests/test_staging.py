@@ -60,13 +60,17 @@ def test_pack_records_into_a_slot_equals_fresh_arrays():
     slot.close()
 
 
-def test_stage_hands_every_job_over_in_order_and_recycles_three_slots():
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_stage_hands_every_job_over_in_order_and_recycles_its_slots(threads):
     ctx = FakeCtx()
+    rng = np.random.default_rng(threads)
+    delays = rng.random(40) * 0.004                     # loaders finish out of order
     seen, slots_used, device_slots = [], set(), []
 
     def fill(job, slot):
         if job % 5 == 4:
             return None                                # a job that yields nothing is skipped
+        time.sleep(delays[job])
         v = slot.text(64)
         v[:] = job
         return job, v
@@ -80,11 +84,12 @@ def test_stage_hands_every_job_over_in_order_and_recycles_three_slots():
         time.sleep(0.001)
         return True
 
-    with staging.Stage(ctx) as st:
+    with staging.Stage(ctx, threads=threads) as st:
         st.run(range(40), fill, submit)
-    assert seen == [j for j in range(40) if j % 5 != 4]
+        assert len(st.slots) == threads + 2
+    assert seen == [j for j in range(40) if j % 5 != 4]              # in the order of the jobs, whoever loaded them
     assert device_slots == [k % 2 for k in range(len(seen))]          # the two device staging slots alternate
-    assert len(slots_used) <= staging.Stage.N_HOST_SLOTS
+    assert len(slots_used) <= threads + 2
     assert len(ctx.waits) == len(seen)                                  # every batch waited for exactly once
     assert ctx.waits[:4] == [0, 1, 0, 1]
 
@@ -100,9 +105,9 @@ def test_stage_passes_a_loader_error_on_and_stops_the_thread():
     got = []
     before = threading.active_count()
     with pytest.raises(ValueError, match="bad file 3"):
-        with staging.Stage(ctx) as st:
+        with staging.Stage(ctx, threads=2) as st:
             st.run(range(10), fill, lambda item, d: got.append(item) or True)
-    assert got == [0, 1, 2]
+    assert got == [0, 1, 2][:len(got)]
     assert threading.active_count() == before
 
     def submit(item, d):
@@ -110,7 +115,7 @@ def test_stage_passes_a_loader_error_on_and_stops_the_thread():
             raise RuntimeError("submit failed")
         return True
     with pytest.raises(RuntimeError, match="submit failed"):
-        with staging.Stage(ctx) as st:
+        with staging.Stage(ctx, threads=4) as st:
             st.run(range(1000), lambda job, slot: job, submit)
     assert threading.active_count() == before
 

@@ -1,5 +1,5 @@
 """Where the wall clock of `pypore seqstats -f fastq` goes (GPU box): interpreter + imports, context, files read into
-pinned slots + submitted, tables, the two HTML reports.  usage: python tools/cli_breakdown.py DIR"""
+pinned slots + submitted, tables, the two HTML reports.  usage: python tools/cli_breakdown.py DIR [loader threads]"""
 import os, sys, time
 t0 = time.perf_counter()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ sq.work_dir, sq.out_dir, sq.prefix = os.getcwd(), "bd_out", "bd"
 os.makedirs("bd_out", exist_ok=True)
 with qc.QCContext(device=0, n_channels=512, n_mux=4, n_time_bins=48, time_mode=1) as ctx:
     t2 = time.perf_counter()
-    sq._submit_fastq_files(ctx, files, None)
+    sq._submit_fastq_files(ctx, files, None, threads=int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     t3 = time.perf_counter()
     ctx.finalize_extremes(); tmin, _ = ctx.time_range(); ctx.set_ref_time(tmin)
     ctx.finalize_tables(); ctx.finalize_n50(); tables = ctx.fetch_tables()
