@@ -681,13 +681,18 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     const uint32_t shift = kDefaultTileShift;
     CHK(ensure_tiles(c, (n + (1ull << shift) - 1) >> shift));
     // the headers are parsed on the auxiliary stream, beside the tile kernel: both need the line table only
+    const bool hdr_after = getenv("PPQC_FQ_HDR_AFTER") != nullptr;
+    if (!hdr_after) {
     HIPCHK(hipEventRecord(c->ev_fq0, s));
     HIPCHK(hipStreamWaitEvent(c->aux, c->ev_fq0, 0));
     HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, c->aux));
     HIPCHK(hipEventRecord(c->ev_fq1, c->aux));
+    }
     // line mode: both classifiers run over the same text, every line is a segment
     BatchView v{text, text, c->fq.line_off, n_lines, n, nullptr, shift, nullptr, nullptr, nullptr};
     HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->dense, c->n_cu, s, true));
+    if (hdr_after) HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, s));
+    else
     HIPCHK(hipStreamWaitEvent(s, c->ev_fq1, 0));
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
                                  c->lut_dev, c->tp.thr_fail, c->tp.fail_q, mux, c->res_buf + c->res_words, s));

@@ -481,9 +481,41 @@ __device__ __forceinline__ void load_part(uint4 (&vb)[NB], uint4 (&vq)[NB], cons
     }
 }
 
+constexpr int kLineGroup = 4;
+
 template <int NB, bool LINE, bool VECB>
 __device__ __forceinline__ void process_batch(const uint4 (&vb)[NB], const uint4 (&vq)[NB], uint32_t s0,
                                               uint32_t n_spans, Walk& w, Acc& acc, const TileCtx& c) {
+    if (LINE && !VECB && NB % kLineGroup == 0) {
+        // Line mode: kLineGroup spans at once when the current line covers all of them -- straight-line code whose LUT
+        // reads and sums the compiler interleaves across the spans, and one set of scalar tests instead of four
+#pragma unroll
+        for (int g = 0; g < NB; g += kLineGroup) {
+            if (s0 + g >= n_spans || w.done) break;
+            const uint32_t gend_rel = (s0 + g + kLineGroup) * kSpan;
+            if (s0 + g + kLineGroup <= n_spans && w.re_rel >= gend_rel) {
+                const uint32_t ty = (uint32_t)w.r & 3u;
+                if (ty == 1u) {
+#pragma unroll
+                    for (int k = 0; k < kLineGroup; ++k) acc_add(acc, vec_sums_bases(vb[g + k]));
+                } else if (ty == 3u) {
+#pragma unroll
+                    for (int k = 0; k < kLineGroup; ++k) acc_add(acc, vec_sums_quals(vb[g + k], c.lut));
+                }
+                if (w.re_rel == gend_rel) {
+                    flush_read(acc, w, c);
+                    walk_advance<false, true>(w, c);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kLineGroup; ++k) {
+                    if (s0 + g + k >= n_spans || w.done) break;
+                    process_span<LINE, VECB>(vb[g + k], vb[g + k], s0 + g + k, w, acc, c);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         if (s0 + i >= n_spans || w.done) break;
@@ -511,24 +543,25 @@ __host__ __device__ inline DenseOut make_dense_out(const uint64_t* base, int par
            ((uint64_t)(T & 8191u) << 51);
 }
 
-template <int NB, bool NT, bool PIPE, bool LINE, bool VECB>
+template <int NB, bool NT, bool PIPE, bool LINE, bool VECB, int WPB = 4>
 __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __restrict__ lut_g, const ReadArrays& ra,
                                           uint64_t read_base, Partial* __restrict__ head, Partial* __restrict__ tail,
                                           uint64_t n_tiles, const DenseOut dz = make_dense_out(nullptr, 0, 1, 64)) {
     __shared__ uint64_t lut[256];
-    __shared__ uint32_t xs[4][64];
-    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __shared__ uint32_t xs[WPB][64];
+#pragma unroll
+    for (int i = 0; i < 4 / WPB; ++i) lut[threadIdx.x + i * 64 * WPB] = lut_g[threadIdx.x + i * 64 * WPB];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+    const uint64_t n_waves = (uint64_t)gridDim.x * WPB;
     const uint64_t kTile = 1ull << b.tile_shift;
     TileCtx c;
     c.read_base = read_base; c.R = b.n_reads; c.off = b.offsets; c.ra = ra; c.head = head; c.lut = lut;
     c.lane = lane; c.lane_off = (uint32_t)lane * kVec; c.xs = &xs[wib][0]; c.line = LINE;
 
-    for (uint64_t t = (uint64_t)blockIdx.x * 4 + wib; t < n_tiles; t += n_waves) {
+    for (uint64_t t = (uint64_t)blockIdx.x * WPB + wib; t < n_tiles; t += n_waves) {
         const uint64_t tile_start = t << b.tile_shift;
         const uint64_t remain = b.n_bytes - tile_start;
         const uint32_t tile_valid = remain < kTile ? (uint32_t)remain : (uint32_t)kTile;   // > 0
@@ -1139,13 +1172,20 @@ __global__ __launch_bounds__(256, (VECB ? 3 : 4)) void tile_kernel(BatchView b, 
     tile_body<NB, NT, PIPE, false, VECB>(b, lut_g, ra, read_base, head, tail, n_tiles, dz);
 }
 
-// Line mode (FASTQ text): one stream.  8 spans per batch at 5 waves per SIMD (95 VGPRs); 16 spans spill (measured
-// 1.0 TB/s of text against 1.27 TB/s for the whole tokenizer path).
+// Line mode (FASTQ text): one stream.  This instantiation serves PPQC_LINE_VECB (all boundaries of a span at once).
 template <int NB, bool VECB>
 __global__ __launch_bounds__(256, (VECB ? 4 : 5))
 void tile_kernel_line(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra, uint64_t read_base,
                       Partial* __restrict__ head, Partial* __restrict__ tail, uint64_t n_tiles, DenseOut dz) {
     tile_body<NB, true, false, true, VECB>(b, lut_g, ra, read_base, head, tail, n_tiles, dz);
+}
+
+// The default line kernel: WPB waves per block, OCC waves per SIMD (launch_tile_kernel says which and why).
+template <int NB, int WPB, int OCC>
+__global__ __launch_bounds__(64 * WPB, OCC)
+void tile_kernel_line_w(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra, uint64_t read_base,
+                        Partial* __restrict__ head, Partial* __restrict__ tail, uint64_t n_tiles, DenseOut dz) {
+    tile_body<NB, true, false, true, false, WPB>(b, lut_g, ra, read_base, head, tail, n_tiles, dz);
 }
 
 // One thread per read: merge the partials of reads that span tiles, define empty reads, then decode the raw sums.
@@ -1294,9 +1334,19 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
             dz = make_dense_out(dl.base, dl.parity, mode, T);
             e = launch_tile_variant<8, true, false, true, true>(b, lut_dev, ra, read_base, head, tail, n_cu, 0, dz, s);
         } else {
-            // (12 or 16 spans in flight per wave at 4 waves per SIMD: 1.95 and 1.92 TB/s of text for the whole path against
-            // 2.04 with 8 at 5 waves -- the line mode is bound by its vector work, like the two-stream kernel)
-            e = launch_tile_variant<8, true, false, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, 0, dz, s);
+            // 4 spans per batch, taken as one group when the line covers them (process_batch), 79 VGPRs = 6 waves per
+            // SIMD, 2 waves per block: 0.70 ms for 3.97 GB of text (5.6 TB/s) against 0.76 for 8 spans, span by span,
+            // at 5 waves.  Tried on the same text, whole path: 1, 2 or 4 waves per block 2.14 / 2.15 / 2.11 TB/s;
+            // two register sets of 8 or 4 spans (the next batch in flight while one is processed) 2.07 / 2.12; groups
+            // of 4 with 8 spans per batch spill at 5 waves (1.85) and give 2.13 at 4; 12 or 16 spans per batch at 4 waves
+            // 1.95 / 1.92 (before the groups).  None of this moves the kernel by more than 2 %: what did was taking the
+            // header kernel from beside it (ppqc_fastq_gpu.hip).
+            const uint64_t n_tiles = (b.n_bytes + (1ull << b.tile_shift) - 1) >> b.tile_shift;
+            uint64_t blocks = (n_tiles + 1) / 2;
+            if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+            hipLaunchKernelGGL((tile_kernel_line_w<kLineGroup, 2, 6>), dim3((unsigned)blocks), dim3(128), 0, s, b, lut_dev, ra,
+                               read_base, head, tail, n_tiles, dz);
+            e = hipGetLastError();
         }
     } else {
         switch (variant) {

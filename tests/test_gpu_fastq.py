@@ -182,3 +182,46 @@ def test_dense_text_takes_the_second_text_pass(qc_mod, c_oracle):
         assert ctx.submit_fastq(sparse) == 500
         _check(ctx.read_stats(), want2)
         assert_tables_equal(ctx.finalize(), wt2)
+
+
+def test_lines_that_end_on_span_group_and_tile_edges_and_odd_headers(qc_mod, c_oracle):
+    """The line-mode tile kernel takes four 1 KiB spans at once when the line covers them: lines that end exactly on a
+    4 KiB group edge, a 1 KiB span edge or a 64 KiB tile edge, and lines a few bytes off them.  The header kernel works on
+    240-byte windows in LDS: longer headers (the one-lane walk), keys at the very start, behind a tab, inside other
+    words, repeated, cut short, and fields that are no numbers."""
+    rng = np.random.default_rng(5)
+    heads = [b"ch=7 start_time=2018-06-03T01:02:03Z",                       # key right behind the '@'
+             b"r xch=9 ch=12\tstart_time=2018-06-04T10:00:00Z ch=99",       # first standalone ch= wins; tab before the key
+             b"r start_time=2018-06-03T01:02 ch=3",                         # time cut short: no start time
+             b"r ch=abc start_time=2018-13-03T01:02:03Z",                   # no digits: channel 0; month 13: no time
+             b"r " + b"x" * 300 + b" ch=44 start_time=2018-06-03T05:00:00Z",  # longer than the LDS window
+             b"r " + b"y" * 219 + b" ch=45 start_time=2018-06-03T06:00:00Z",  # just inside it
+             b"r " + b"y" * 225 + b" ch=46 start_time=2018-06-03T06:00:00Z   ",
+             b"r ch=47 start_time=2018-06-03 07:00:00"]                     # blank instead of 'T'
+    out, pos = [], 0
+    edges = [4096, 1024, 65536, 4096, 8192, 4096 * 3, 65536 * 2]
+    for i in range(160):
+        title = heads[i % len(heads)] if i % 3 == 0 else b"read%d ch=%d start_time=2018-06-03T%02d:00:00Z" % (i, 1 + i % 512, i % 24)
+        h = len(title) + 2                                  # '@' + title + '\n'
+        E = edges[i % len(edges)]
+        d = int(rng.integers(-2, 3)) if i % 4 == 3 else 0   # some lines miss the edge by a byte or two
+        if i % 2 == 0:                                      # the sequence line ends on the edge
+            L = (-(pos + h + 1)) % E + d
+        else:                                               # the quality line does
+            if (pos + h + 4) % 2:
+                title += b" "; h += 1
+            L = ((-(pos + h + 4)) % E) // 2 + d
+        L = max(L, 0) + (E if L < 40 else 0)
+        seq = bytes(rng.choice(ALPH, L)); qual = bytes(rng.integers(33, 127, L, dtype=np.uint8))
+        rec = b"@" + title + b"\n" + seq + b"\n+\n" + qual + b"\n"
+        out.append(rec); pos += len(rec)
+    text = b"".join(out)
+    p, want, wt = _host_path(qc_mod, c_oracle, text)
+    assert p["n_reads"] == 160
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        assert ctx.submit_fastq(text) == 160
+        got = ctx.read_stats()
+        tables = ctx.finalize()
+    _check(got, want)
+    assert_tables_equal(tables, wt)      # channels and start times: the host packer's, through the tables
+    assert int(tables["totals"][7]) == int(np.sum((p["channel"] < 1) | (p["channel"] > 512))) > 0
