@@ -156,7 +156,7 @@ struct ppqc_ctx {
     bool pre_run = false;   // ... and the finalize in progress relies on it (set by ppqc_finalize_extremes)
     bool n50_early = false; // ppqc_n50_select_early has left the N50 of the run's reads (no batch since)
     hipEvent_t ev_pre = nullptr;   // behind the newest of those kernels (auxiliary stream)
-    hipEvent_t ev_fq0 = nullptr, ev_fq1 = nullptr;   // FASTQ text: line table ready / headers parsed (auxiliary stream)
+    hipEvent_t ev_fq = nullptr;    // FASTQ text: the newlines are counted (the host waits for it)
     hipEvent_t ev_clean = nullptr; // behind the clear of the result buffer (ppqc_reset / ppqc_create, main stream)
     uint64_t* maxlen_host = nullptr;   // a few pinned scratch words (line count of the GPU tokenizer)
     uint64_t* m1 = nullptr;            // time_mode 1 across ranks: [first | ties | days] (ppqc_mode1_dist_view)
@@ -365,8 +365,7 @@ static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_max, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_clean, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_fq0, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_fq1, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fq, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->ev_join));
     HIPCHK(hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
@@ -464,8 +463,7 @@ int ppqc_destroy(ppqc_ctx* c) {
     if (c->ev_max) (void)hipEventDestroy(c->ev_max);
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     if (c->ev_clean) (void)hipEventDestroy(c->ev_clean);
-    if (c->ev_fq0) (void)hipEventDestroy(c->ev_fq0);
-    if (c->ev_fq1) (void)hipEventDestroy(c->ev_fq1);
+    if (c->ev_fq) (void)hipEventDestroy(c->ev_fq);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_reads) (void)hipEventDestroy(c->ev_reads);
@@ -657,12 +655,9 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
         CHK(grow(&c->fq.block_sums, 0, nl_scan_block_words(cap), s));
         c->cap_chunks = cap;
     }
-    HIPCHK(launch_nl_scan(text, n, c->fq, s));
     uint64_t* h = c->maxlen_host;   // pinned scratch words [1] = newlines, [2] = chunks with too many odd vectors, [3] = last byte
-    h[3] = 0;
-    HIPCHK(hipMemcpyAsync(&h[1], c->fq.prefix + n_chunks, 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&h[3], text + n - 1, 1, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(launch_nl_scan(text, n, c->fq, h + 1, c->ev_fq, s));   // the scan's top kernel writes them
+    HIPCHK(hipEventSynchronize(c->ev_fq));
     const uint64_t n_lines = h[1] + (((uint8_t)h[3]) != '\n' ? 1 : 0);
     const bool sparse = h[2] == 0;
     if (n_lines % 4 != 0)
@@ -680,20 +675,13 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     CHK(ensure_reads(c, c->n_reads + R));
     const uint32_t shift = kDefaultTileShift;
     CHK(ensure_tiles(c, (n + (1ull << shift) - 1) >> shift));
-    // the headers are parsed on the auxiliary stream, beside the tile kernel: both need the line table only
-    const bool hdr_after = getenv("PPQC_FQ_HDR_AFTER") != nullptr;
-    if (!hdr_after) {
-    HIPCHK(hipEventRecord(c->ev_fq0, s));
-    HIPCHK(hipStreamWaitEvent(c->aux, c->ev_fq0, 0));
-    HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, c->aux));
-    HIPCHK(hipEventRecord(c->ev_fq1, c->aux));
-    }
+    // The headers need the line table only.  Their kernel runs in front of the tile kernel on the same stream: beside it
+    // on the auxiliary stream (also at the highest stream priority) its blocks trickle in between the tile kernel's for
+    // the whole 0.72 ms and fastq_finalize waits 50 us for the last of them.
+    HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, s));
     // line mode: both classifiers run over the same text, every line is a segment
     BatchView v{text, text, c->fq.line_off, n_lines, n, nullptr, shift, nullptr, nullptr, nullptr};
     HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->dense, c->n_cu, s, true));
-    if (hdr_after) HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, s));
-    else
-    HIPCHK(hipStreamWaitEvent(s, c->ev_fq1, 0));
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
                                  c->lut_dev, c->tp.thr_fail, c->tp.fail_q, mux, c->res_buf + c->res_words, s));
     c->n_reads += R;

@@ -153,8 +153,11 @@ __global__ __launch_bounds__(256) void nl_blocksum_kernel(const uint32_t* __rest
 }
 
 // single block: exclusive scan of the block sums in place; grand total -> *total
+// Also hands the host what it waits for (pinned words host_out[0..2]: newlines, chunks whose entry list overflowed, the
+// last byte of the text), so that no copy command stands between this kernel and the host.
 __global__ __launch_bounds__(256) void nl_scan_top_kernel(uint64_t* __restrict__ bsum, uint64_t nblocks,
-                                                          uint64_t* __restrict__ total) {
+                                                          uint64_t* __restrict__ total, uint64_t* __restrict__ host_out,
+                                                          const uint8_t* __restrict__ last_byte) {
     __shared__ uint64_t part[256];
     const uint32_t t = threadIdx.x;
     const uint64_t seg = (nblocks + 255) / 256;
@@ -167,6 +170,12 @@ __global__ __launch_bounds__(256) void nl_scan_top_kernel(uint64_t* __restrict__
         uint64_t run = 0;
         for (int i = 0; i < 256; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; }
         *total = run;
+        if (host_out) {
+            host_out[0] = run;
+            host_out[1] = total[1];
+            host_out[2] = *last_byte;
+            __threadfence_system();
+        }
     }
     __syncthreads();
     uint64_t run = part[t];
@@ -298,7 +307,8 @@ __global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict_
 
 // Pass 1 and the scan: counts, entries and the chunks' line numbers; fs.prefix[n_chunks] = newlines of the text,
 // fs.prefix[n_chunks + 1] = chunks whose entry list overflowed.
-hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, hipStream_t s) {
+hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, uint64_t* host_out, hipEvent_t counted,
+                          hipStream_t s) {
     const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
     hipError_t e = hipMemsetAsync(fs.prefix + n_chunks, 0, 16, s);
     if (e != hipSuccess || n_chunks == 0) return e;
@@ -306,7 +316,12 @@ hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& f
                        fs.entries, n_chunks, fs.prefix + n_chunks + 1);
     const uint64_t nblocks = (n_chunks + kScanBlock - 1) / kScanBlock;
     hipLaunchKernelGGL(nl_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, fs.counts, n_chunks, fs.block_sums);
-    hipLaunchKernelGGL(nl_scan_top_kernel, dim3(1), dim3(256), 0, s, fs.block_sums, nblocks, fs.prefix + n_chunks);
+    hipLaunchKernelGGL(nl_scan_top_kernel, dim3(1), dim3(256), 0, s, fs.block_sums, nblocks, fs.prefix + n_chunks, host_out,
+                       text + n - 1);
+    if (counted) {   // the host may go on from here while the chunks' line numbers are written
+        e = hipEventRecord(counted, s);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(nl_scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, fs.counts, n_chunks,
                        fs.block_sums, fs.prefix);
     return hipGetLastError();
@@ -331,17 +346,6 @@ hipError_t launch_nl_place(const uint8_t* text, uint64_t n, uint64_t n_lines, bo
 
 __device__ __forceinline__ bool is_space(uint8_t c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
 
-// " key=" at the start of the header or after a blank: returns the position after the key, or e if absent
-__device__ inline uint64_t find_field(const uint8_t* __restrict__ t, uint64_t a, uint64_t e, const char* key, int klen) {
-    for (uint64_t i = a; i + klen <= e; ++i) {
-        if (i != a && t[i - 1] != ' ' && t[i - 1] != '\t') continue;
-        bool ok = true;
-        for (int k = 0; k < klen && ok; ++k) ok = t[i + k] == (uint8_t)key[k];
-        if (ok) return i + klen;
-    }
-    return e;
-}
-
 __device__ inline int64_t days_from_civil(int64_t y, unsigned m, unsigned d) {
     y -= m <= 2;
     const int64_t era = (y >= 0 ? y : y - 399) / 400;
@@ -351,125 +355,93 @@ __device__ inline int64_t days_from_civil(int64_t y, unsigned m, unsigned d) {
     return era * 146097 + (int64_t)doe - 719468;
 }
 
-// "YYYY-MM-DDTHH:MM:SS" at t[p..e): seconds since the epoch (UTC), INT64_MIN if it does not parse
-__device__ inline int64_t parse_iso8601(const uint8_t* __restrict__ t, uint64_t p, uint64_t e) {
-    if (e - p < 19) return INT64_MIN;
-    int64_t f[6];
-    const int beg[6] = {0, 5, 8, 11, 14, 17}, end[6] = {4, 7, 10, 13, 16, 19};
-    for (int k = 0; k < 6; ++k) {
-        int64_t x = 0;
-        for (int i = beg[k]; i < end[k]; ++i) {
-            const uint8_t c = t[p + i];
-            if (c < '0' || c > '9') return INT64_MIN;
-            x = x * 10 + (c - '0');
-        }
-        f[k] = x;
-    }
-    if (t[p + 4] != '-' || t[p + 7] != '-' || (t[p + 10] != 'T' && t[p + 10] != ' ') || t[p + 13] != ':' || t[p + 16] != ':')
-        return INT64_MIN;
-    if (f[1] < 1 || f[1] > 12 || f[2] < 1 || f[2] > 31) return INT64_MIN;
-    return days_from_civil(f[0], (unsigned)f[1], (unsigned)f[2]) * 86400 + f[3] * 3600 + f[4] * 60 + f[5];
-}
-
 // The albacore header fields (the reference reads ch= at lib/seq_routines.py:51) need the line table only, not the sums: a
-// kernel of its own that runs beside the line-mode tile kernel on the auxiliary stream.  Sixteen lanes per record: the
-// header goes to LDS in 16-byte granules (one load per lane, aligned, so a granule that holds a byte of the text lies in
-// that byte's page), every lane looks at 16 positions for the end of the stripped line and for the two keys, and two
-// lanes parse the digits out of LDS.  (One thread per record walking its header through about 150 dependent global
-// loads took 0.16 ms for 200 000 records alone and 0.35 ms beside the tile kernel, which it slowed from 0.70 to
-// 0.89 ms.)  A header of more than kHdrFast bytes is walked by one lane as before.  fastq_finalize overrides both fields
-// for a malformed record.
-constexpr int kHdrLanes = 16, kHdrBytes = 16 * kHdrLanes, kHdrFast = kHdrBytes - 16;
+// kernel of its own in front of the line-mode tile kernel.  One thread per record streams its header through registers
+// in aligned 16-byte granules (a granule that holds a byte of the text lies in that byte's page; the next one is in
+// flight while one is looked at) and feeds every byte to two small automata, one per key: a key starts behind the '@'
+// or behind a blank or tab and only its first occurrence counts, "ch=" is followed by decimal digits, "start_time=" by
+// the 19 characters YYYY-MM-DD(T or blank)HH:MM:SS (the rules of the host packer, ppqc_fastq.cpp).  White space at the end of the line takes part in no match, so
+// the stripped end need not be known.  0.02 ms for 200 000 records; walking the header through about 150 dependent byte
+// loads took 0.16 ms, sixteen lanes per record over an LDS window 0.08 ms; beside the tile kernel on the auxiliary
+// stream either one cost the tile kernel more than it took alone.  fastq_finalize overrides both fields for a malformed
+// record.
+struct HeaderScan {
+    int cm = 0;         // "ch=": 0..2 characters matched (0: a key may start here), 3 digits follow, 4 done, -1 no key before the next blank
+    int ts = 0;         // "start_time=": 0..10 matched, 11 the time follows, 12 parsed, 13 does not parse, -1 as above
+    int ti = 0;         // characters of the time seen
+    uint32_t ch = 0;
+    uint64_t tacc = 0;  // YYYYMMDDHHMMSS as one decimal number
 
-struct HeaderFields { uint32_t ch; int64_t tm; };
-
-__device__ inline HeaderFields header_fields_serial(const uint8_t* __restrict__ text, uint64_t a, uint64_t e) {
-    while (e > a && is_space(text[e - 1])) --e;
-    HeaderFields h{0, INT64_MIN};
-    if (e > a) {
-        uint64_t p = find_field(text, a + 1, e, "ch=", 3);
-        for (; p < e && text[p] >= '0' && text[p] <= '9'; ++p) h.ch = h.ch * 10 + (uint32_t)(text[p] - '0');
-        p = find_field(text, a + 1, e, "start_time=", 11);
-        if (p < e) h.tm = parse_iso8601(text, p, e);
+    __device__ __forceinline__ void step(uint32_t c) {
+        const bool blank = c == ' ' || c == '\t';
+        const uint32_t d = c - '0';
+        const bool digit = d <= 9u;
+        if (cm == 3) {
+            if (digit) ch = ch * 10u + d; else cm = 4;
+        } else if (cm < 3) {
+            const uint32_t want = (0x3D6863u >> (8 * (cm < 0 ? 0 : cm))) & 0xffu;   // "ch="
+            cm = (cm >= 0 && c == want) ? cm + 1 : (blank ? 0 : -1);
+        }
+        if (ts == 11) {
+            const bool sep_pos = ti == 4 || ti == 7 || ti == 10 || ti == 13 || ti == 16;
+            const bool sep_ok = ti == 10 ? (c == 'T' || c == ' ') : (ti < 10 ? c == '-' : c == ':');
+            if (sep_pos ? sep_ok : digit) {
+                if (!sep_pos) tacc = tacc * 10u + d;
+                if (++ti == 19) ts = 12;
+            } else {
+                ts = 13;
+            }
+        } else if (ts < 11) {
+            const int q = ts < 0 ? 0 : ts;
+            const uint64_t K0 = 0x69745F7472617473ull, K1 = 0x3D656Dull;   // "start_ti", "me="
+            const uint32_t want = (uint32_t)((q < 8 ? K0 >> (8 * q) : K1 >> (8 * (q - 8))) & 0xffu);
+            ts = (ts >= 0 && c == want) ? ts + 1 : (blank ? 0 : -1);
+        }
     }
-    return h;
-}
-
-__device__ __forceinline__ int group_min(int v) {   // over the 16 lanes of a record
-#pragma unroll
-    for (int o = 1; o < kHdrLanes; o <<= 1) {
-        const int u = __shfl_xor(v, o, kHdrLanes);
-        v = u < v ? u : v;
+    __device__ __forceinline__ bool done() const { return cm == 4 && ts >= 12; }
+    __device__ __forceinline__ int64_t time() const {
+        if (ts != 12) return INT64_MIN;
+        uint64_t x = tacc;
+        const int64_t ss = (int64_t)(x % 100); x /= 100;
+        const int64_t mi = (int64_t)(x % 100); x /= 100;
+        const int64_t hh = (int64_t)(x % 100); x /= 100;
+        const unsigned dd = (unsigned)(x % 100); x /= 100;
+        const unsigned mo = (unsigned)(x % 100); x /= 100;
+        if (mo < 1 || mo > 12 || dd < 1 || dd > 31) return INT64_MIN;
+        return days_from_civil((int64_t)x, mo, dd) * 86400 + hh * 3600 + mi * 60 + ss;
     }
-    return v;
-}
+};
 
 __global__ __launch_bounds__(256) void fastq_header_kernel(const uint8_t* __restrict__ text, uint64_t n_records,
                                                            const uint64_t* __restrict__ lo, ReadArrays ra,
                                                            uint64_t read_base, uint8_t mux) {
-    __shared__ __align__(16) uint8_t hb[256 / kHdrLanes][kHdrBytes + 16];
-    const int grp = threadIdx.x / kHdrLanes, j = threadIdx.x % kHdrLanes;
-    const uint64_t r = (uint64_t)blockIdx.x * (256 / kHdrLanes) + grp;
-    const bool live = r < n_records;
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_records) return;
     const uint64_t g = read_base + r;
-    uint64_t a = 0, e0 = 0;
-    if (live) { a = lo[4 * r]; e0 = lo[4 * r + 1]; }
-    const uint64_t len = e0 - a;
-    const bool fast = live && len <= (uint64_t)kHdrFast;
-    uint8_t* b = &hb[grp][0];
-    // granule j of the 16-byte aligned window that starts at or below text + a; sh = where the header starts in it
-    const uintptr_t base = (uintptr_t)(text + a);
-    const int sh = (int)(base & 15u);
-    if (fast) {
-        const uintptr_t ga = (base & ~(uintptr_t)15) + 16u * (unsigned)j;
-        if (ga < (uintptr_t)(text + e0)) *reinterpret_cast<uint4*>(b + 16 * j) = *reinterpret_cast<const uint4*>(ga);
-    }
-    __syncthreads();
-    if (!live) return;
-    if (!fast) {
-        if (j == 0) {
-            const HeaderFields h = header_fields_serial(text, a, e0);
-            ra.channel[g] = h.ch; ra.mux[g] = mux; ra.time[g] = h.tm;
-        }
-        return;
-    }
-    const uint8_t* hdr = b + sh;   // hdr[k] = text[a + k], k < len
-    const int L = (int)len;
-    // the stripped end: one past the last byte that is no white space
-    int last = -1;
+    const uint64_t a = lo[4 * r], e0 = lo[4 * r + 1];
+    const int64_t len = (int64_t)(e0 - a);
+    const uintptr_t base = (uintptr_t)(text + a), endp = (uintptr_t)(text + e0);
+    uintptr_t ga = base & ~(uintptr_t)15;
+    int64_t k = -(int64_t)(base & 15u);   // index in the header of the granule's first byte
+    HeaderScan h;
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    if (ga < endp) cur = *reinterpret_cast<const uint4*>(ga);
+    while (ga < endp) {
+        const uintptr_t gn = ga + 16;
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (gn < endp) nxt = *reinterpret_cast<const uint4*>(gn);
+        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int k = 16 * j + t;
-        if (k < L && !is_space(hdr[k])) last = k;
-    }
-    const int e = -group_min(-(last + 1));
-    // first position of each key at the start of the header (k = 1, behind the '@') or behind a blank
-    int p_ch = e, p_tm = e;
-    for (int t = 0; t < 16; ++t) {
-        const int k = 16 * j + t;
-        if (k < 1 || k >= e) continue;
-        const uint8_t c = hdr[k];
-        if (c != 'c' && c != 's') continue;
-        if (k != 1 && hdr[k - 1] != ' ' && hdr[k - 1] != '\t') continue;
-        if (c == 'c') {
-            if (p_ch == e && k + 3 <= e && hdr[k + 1] == 'h' && hdr[k + 2] == '=') p_ch = k + 3;
-        } else if (p_tm == e && k + 11 <= e) {
-            const char* key = "start_time=";
-            bool ok = true;
-            for (int q = 1; q < 11 && ok; ++q) ok = hdr[k + q] == (uint8_t)key[q];
-            if (ok) p_tm = k + 11;
+        for (int t = 0; t < 16; ++t) {
+            const int64_t kk = k + t;
+            if (kk >= 1 && kk < len) h.step((w[t >> 2] >> (8 * (t & 3))) & 0xffu);   // byte 0 is the '@'
         }
+        if (h.done()) break;
+        cur = nxt; ga = gn; k += 16;
     }
-    p_ch = group_min(p_ch);
-    p_tm = group_min(p_tm);
-    if (j == 0) {
-        uint32_t ch = 0;
-        for (int p = p_ch; p < e && hdr[p] >= '0' && hdr[p] <= '9'; ++p) ch = ch * 10 + (uint32_t)(hdr[p] - '0');
-        ra.channel[g] = ch;
-        ra.mux[g] = mux;
-    } else if (j == 1) {
-        ra.time[g] = (e > 0 && p_tm < e) ? parse_iso8601(hdr, (uint64_t)p_tm, (uint64_t)e) : INT64_MIN;
-    }
+    ra.channel[g] = h.ch;
+    ra.mux[g] = mux;
+    ra.time[g] = h.time();
 }
 
 __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __restrict__ text, uint64_t n,
@@ -538,9 +510,8 @@ __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __re
 hipError_t launch_fastq_header(const uint8_t* text, uint64_t n_records, const uint64_t* line_off, ReadArrays ra,
                                uint64_t read_base, uint8_t mux, hipStream_t s) {
     if (n_records == 0) return hipSuccess;
-    const uint64_t per_block = 256 / kHdrLanes;
-    hipLaunchKernelGGL(fastq_header_kernel, dim3((unsigned)((n_records + per_block - 1) / per_block)), dim3(256), 0, s, text,
-                       n_records, line_off, ra, read_base, mux);
+    hipLaunchKernelGGL(fastq_header_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n_records,
+                       line_off, ra, read_base, mux);
     return hipGetLastError();
 }
 

@@ -162,7 +162,8 @@ struct FastqScratch {
     uint64_t* line_off;     // n_lines + 1 line starts (the CSR offsets of the line-mode tile kernel)
 };
 uint64_t nl_scan_block_words(uint64_t n_chunks);
-hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, hipStream_t s);
+hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, uint64_t* host_out, hipEvent_t counted,
+                          hipStream_t s);
 hipError_t launch_nl_place(const uint8_t* text, uint64_t n, uint64_t n_lines, bool sparse, const FastqScratch& fs,
                            uint64_t* errors, hipStream_t s);
 // one thread per record: validates the four lines, strips line ends, merges the line sums into the per-read arrays,
