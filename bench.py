@@ -607,12 +607,12 @@ def fastq_mode(a, ctx, torch, off, ch, t, d_bases, d_quals):
         dt = (time.perf_counter() - t0) / a.steps
         assert int(tab["totals"][0]) == R and int(tab["totals"][1]) == nb and int(tab["totals"][7]) == 0
         res[name] = {"ms": round(dt * 1e3, 3), "Gbases_per_s": round(nb / dt / 1e9, 2), "text_GBps": round(total / dt / 1e9, 2)}
-        return tab
+        return {k: np.array(v) for k, v in tab.items()}   # the next path overwrites the pinned buffer the views show
 
     def resident():      # whole text already in HBM, one call
         ctx.reset()
         ctx.submit_fastq_device(d_text.data_ptr(), total)
-        return ctx.finalize()
+        return ctx.finalize(copy=False)   # like the headline step: the tables as views of the pinned result buffer
 
     def streamed():      # pinned host text, file by file through the two staging slots
         ctx.reset()

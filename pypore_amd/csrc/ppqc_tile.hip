@@ -148,11 +148,17 @@ __device__ __forceinline__ uint64_t find_read(const uint64_t* __restrict__ off, 
 // per lane and tile gcs, n <= 2^10 and qb <= 2^18, and the error sum (< 2^62 per lane) goes in three 21-bit pieces
 // whose wave sums stay below 2^27.  S = E0 + E1 * 2^21 + E2 * 2^42 is stored as lo = E0 + (E1 << 21), hi = E2 << 10
 // (S = hi * 2^32 + lo; finalize_reads normalises the split).
-__device__ __forceinline__ void flush(Acc& acc, int lane, uint64_t* cnt, uint64_t* hi, uint64_t* lo) {
-    const uint32_t G = wave_sum_u32(acc.gcs), N = wave_sum_u32(acc.n), Q = wave_sum_u32(acc.qb);
-    const uint32_t E0 = wave_sum_u32((uint32_t)acc.err & 0x1FFFFFu);
-    const uint32_t E1 = wave_sum_u32((uint32_t)(acc.err >> 21) & 0x1FFFFFu);
-    const uint32_t E2 = wave_sum_u32((uint32_t)(acc.err >> 42));
+// kind (wave-uniform; line mode): 1 = a sequence line, only G and N are ever read; 2 = a quality line, only Q and the
+// error sum are -- the other reductions are left out and their fields stored as zero.
+__device__ __forceinline__ void flush(Acc& acc, int lane, uint64_t* cnt, uint64_t* hi, uint64_t* lo, int kind = 0) {
+    uint32_t G = 0, N = 0, Q = 0, E0 = 0, E1 = 0, E2 = 0;
+    if (kind != 2) { G = wave_sum_u32(acc.gcs); N = wave_sum_u32(acc.n); }
+    if (kind != 1) {
+        Q = wave_sum_u32(acc.qb);
+        E0 = wave_sum_u32((uint32_t)acc.err & 0x1FFFFFu);
+        E1 = wave_sum_u32((uint32_t)(acc.err >> 21) & 0x1FFFFFu);
+        E2 = wave_sum_u32((uint32_t)(acc.err >> 42));
+    }
     if (lane == 0) {
         *cnt = pack_cnt(G, N, Q);
         *hi = (uint64_t)E2 << 10;
@@ -236,7 +242,7 @@ __device__ __forceinline__ void flush_read(Acc& acc, const Walk& w, const TileCt
     Partial* p = &c.head[c.t];
     const uint64_t ri = c.read_base + w.r;
     flush(acc, c.lane, whole ? &c.ra.rec_cnt[ri] : &p->cnt, whole ? &c.ra.rec_hi[ri] : &p->hi,
-          whole ? &c.ra.rec_lo[ri] : &p->lo);
+          whole ? &c.ra.rec_lo[ri] : &p->lo, c.line ? ((w.r & 3) == 1 ? 1 : 2) : 0);
 }
 
 // The boundaries of a span one after the other, with the byte-masked part done byte-parallel (the default kernel).
@@ -622,7 +628,7 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
         // a read that continues into the next tile leaves a partial: tail if it started here, else head
         if (!w.done && w.rs < tile_start + kTile && w.re > tile_start + kTile && !(LINE && !(w.r & 1))) {
             Partial* p = w.rs >= tile_start ? &tail[t] : &head[t];
-            flush(acc, lane, &p->cnt, &p->hi, &p->lo);
+            flush(acc, lane, &p->cnt, &p->hi, &p->lo, LINE ? ((w.r & 3) == 1 ? 1 : 2) : 0);
         }
     }
 }
