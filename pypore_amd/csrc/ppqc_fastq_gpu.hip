@@ -209,36 +209,51 @@ __global__ __launch_bounds__(256) void nl_scan_apply_kernel(const uint32_t* __re
 }
 
 
-// half a wave per chunk: lane j of the half owns the chunk's j-th odd vector
+// half a wave per kPlaceIlp consecutive chunks: lane j of the half owns the j-th odd vector of each of them.  The loads
+// of all its chunks are requested before the first is looked at: the kernel is a chain of three dependent loads per
+// chunk (count, entry, then the stores), and one chunk per half-wave left it bound by that latency (51 us for 485 000
+// chunks).
+constexpr int kPlaceIlp = 4;
 __global__ __launch_bounds__(256) void nl_place_kernel(const uint64_t* __restrict__ prefix, const uint32_t* __restrict__ n_entries,
                                                        const uint64_t* __restrict__ entries, uint64_t n_chunks,
                                                        uint64_t* __restrict__ line_off, uint64_t n, uint64_t n_lines,
                                                        uint64_t* __restrict__ errors) {
     const int lane = threadIdx.x & 63, j = lane & 31;
-    const uint64_t chunk = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (uint64_t)(lane >> 5);
+    const uint64_t chunk0 = (((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (uint64_t)(lane >> 5)) * kPlaceIlp;
     if (blockIdx.x == 0 && threadIdx.x == 0) { line_off[0] = 0; line_off[n_lines] = n; }
-    const bool live = chunk < n_chunks;
-    const uint32_t ne = live ? n_entries[chunk] : 0;
-    const uint64_t e = (live && (uint32_t)j < ne) ? entries[chunk * kNlEntries + j] : 0;
-    uint32_t bits = (uint32_t)e & 0xFFFFu;
-    const uint32_t bad = (uint32_t)(e >> 16) & 0xFFFFu;
-    const uint32_t c = __popc(bits);
-    // exclusive prefix of the newline counts inside each half: the full-wave scan, minus what the lower half added
-    const uint32_t inc = wave_scan_incl_u32(c);
-    const uint32_t low = (uint32_t)__builtin_amdgcn_readlane((int)inc, 31);
-    uint64_t k = (live ? prefix[chunk] : 0) + (inc - c) - (lane >= 32 ? low : 0u);   // the line the vector starts in
-    const uint64_t pos = chunk * kNlChunk + (uint64_t)(uint32_t)(e >> 32) * kVec;
-    uint32_t nbad = 0;
-    // quality lines are the lines 3 (mod 4): count their invalid bytes (what SeqIO rejects, lib/seq_routines.py:50)
-    for (uint32_t m = bad; m; m &= m - 1) {
-        const int b = __ffs((int)m) - 1;
-        nbad += ((k + __popc(bits & ((1u << b) - 1u))) & 3) == 3;
+    uint32_t ne[kPlaceIlp];
+    uint64_t pf[kPlaceIlp], en[kPlaceIlp];
+#pragma unroll
+    for (int q = 0; q < kPlaceIlp; ++q) {
+        const bool live = chunk0 + q < n_chunks;
+        ne[q] = live ? n_entries[chunk0 + q] : 0;
+        pf[q] = live ? prefix[chunk0 + q] : 0;
     }
-    while (bits) {
-        const int b = __ffs((int)bits) - 1;
-        bits &= bits - 1;
-        if (k + 1 < n_lines) line_off[k + 1] = pos + (uint64_t)b + 1;   // a final newline at n - 1 is line_off[n_lines] = n
-        ++k;
+#pragma unroll
+    for (int q = 0; q < kPlaceIlp; ++q) en[q] = (uint32_t)j < ne[q] ? entries[(chunk0 + q) * kNlEntries + j] : 0;
+    uint32_t nbad = 0;
+#pragma unroll
+    for (int q = 0; q < kPlaceIlp; ++q) {
+        const uint64_t e = en[q];
+        uint32_t bits = (uint32_t)e & 0xFFFFu;
+        const uint32_t bad = (uint32_t)(e >> 16) & 0xFFFFu;
+        const uint32_t c = __popc(bits);
+        // exclusive prefix of the newline counts inside each half: the full-wave scan, minus what the lower half added
+        const uint32_t inc = wave_scan_incl_u32(c);
+        const uint32_t low = (uint32_t)__builtin_amdgcn_readlane((int)inc, 31);
+        uint64_t k = pf[q] + (inc - c) - (lane >= 32 ? low : 0u);   // the line the vector starts in
+        const uint64_t pos = (chunk0 + q) * kNlChunk + (uint64_t)(uint32_t)(e >> 32) * kVec;
+        // quality lines are the lines 3 (mod 4): count their invalid bytes (what SeqIO rejects, lib/seq_routines.py:50)
+        for (uint32_t m = bad; m; m &= m - 1) {
+            const int b = __ffs((int)m) - 1;
+            nbad += ((k + __popc(bits & ((1u << b) - 1u))) & 3) == 3;
+        }
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            if (k + 1 < n_lines) line_off[k + 1] = pos + (uint64_t)b + 1;   // a final newline at n - 1 is line_off[n_lines] = n
+            ++k;
+        }
     }
     nbad = wave_sum_u32(nbad);
     if (lane == 0 && nbad) atomicAdd((unsigned long long*)&errors[3], (unsigned long long)nbad);
@@ -333,7 +348,7 @@ hipError_t launch_nl_place(const uint8_t* text, uint64_t n, uint64_t n_lines, bo
                            uint64_t* errors, hipStream_t s) {
     const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
     if (sparse) {
-        const uint64_t blocks = n_chunks ? (n_chunks + 7) / 8 : 1;
+        const uint64_t blocks = n_chunks ? (n_chunks + 8 * kPlaceIlp - 1) / (8 * kPlaceIlp) : 1;
         hipLaunchKernelGGL(nl_place_kernel, dim3((unsigned)blocks), dim3(256), 0, s, fs.prefix, fs.n_entries, fs.entries,
                            n_chunks, fs.line_off, n, n_lines, errors);
     } else {
