@@ -378,8 +378,10 @@ __device__ inline int64_t days_from_civil(int64_t y, unsigned m, unsigned d) {
 // the 19 characters YYYY-MM-DD(T or blank)HH:MM:SS (the rules of the host packer, ppqc_fastq.cpp).  White space at the end of the line takes part in no match, so
 // the stripped end need not be known.  0.02 ms for 200 000 records; walking the header through about 150 dependent byte
 // loads took 0.16 ms, sixteen lanes per record over an LDS window 0.08 ms; beside the tile kernel on the auxiliary
-// stream either one cost the tile kernel more than it took alone.  fastq_finalize overrides both fields for a malformed
-// record.
+// stream either one cost the tile kernel more than it took alone.  Tried on this version and slower for the whole path
+// (tools/ab_fastq.sh, one box): four lanes per record, each looking for the keys that start in its quarter of the header
+// (+26 us: three more loads in front of the first granule and four times the threads), and blocks of four granules with
+// one block in flight (+10 us).  fastq_finalize overrides both fields for a malformed record.
 struct HeaderScan {
     int cm = 0;         // "ch=": 0..2 characters matched (0: a key may start here), 3 digits follow, 4 done, -1 no key before the next blank
     int ts = 0;         // "start_time=": 0..10 matched, 11 the time follows, 12 parsed, 13 does not parse, -1 as above

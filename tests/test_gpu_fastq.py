@@ -225,3 +225,37 @@ def test_lines_that_end_on_span_group_and_tile_edges_and_odd_headers(qc_mod, c_o
     _check(got, want)
     assert_tables_equal(tables, wt)      # channels and start times: the host packer's, through the tables
     assert int(tables["totals"][7]) == int(np.sum((p["channel"] < 1) | (p["channel"] > 512))) > 0
+
+
+def test_header_fuzz_against_the_host_packer(qc_mod, c_oracle):
+    """Random token soups in the header (keys whole, cut, glued to other words, repeated, behind tabs, at every offset,
+    fields running into the line end, LF and CRLF) must give the channels and start times of the host packer -- through the
+    per-channel and per-hour tables, with one base per read so that every table cell counts reads."""
+    rng = np.random.default_rng(77)
+    toks = [b"ch=%d", b"xch=%d", b"ch=", b"ch", b"c", b"h=%d", b"ch=%dq", b"start_time=2018-06-03T%02d:10:00Z",
+            b"start_time=2018-06-04 %02d:00:00", b"start_time=2018-06-03T%02d", b"start_time=", b"start_tim=2018-06-03T%02d:00:00Z",
+            b"xstart_time=2018-06-03T%02d:00:00Z", b"runid=%032x", b"read=%d", b"s", b"st", b"", b"start_time=2018-06-03T%02d:61:00Z"]
+    recs = []
+    for i in range(3000):
+        parts = []
+        for _ in range(int(rng.integers(0, 9))):
+            t = toks[int(rng.integers(0, len(toks)))]
+            if b"%" in t:
+                t = t % (int(rng.integers(0, 24)) if b"start" in t else int(rng.integers(0, 600)))
+            parts.append(t)
+            parts.append(rng.choice([b" ", b"\t", b"  ", b" \t"]))
+        title = b"".join(parts)
+        if i % 3 == 0:
+            title = title.rstrip()          # a field that runs into the line end
+        nl = b"\r\n" if i % 7 == 0 else b"\n"
+        recs.append(b"@" + title + nl + b"G" + nl + b"+" + nl + b"I" + nl)
+    text = b"".join(recs)
+    p, want, wt = _host_path(qc_mod, c_oracle, text)
+    assert p["n_reads"] == 3000
+    assert len(set(p["channel"].tolist())) > 200 and len(set(p["start_time"].tolist())) > 20
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        assert ctx.submit_fastq(text) == 3000
+        got = ctx.read_stats()
+        tables = ctx.finalize()
+    _check(got, want)
+    assert_tables_equal(tables, wt)
