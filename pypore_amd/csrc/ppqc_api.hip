@@ -143,6 +143,7 @@ struct ppqc_ctx {
     FastqScratch fq{};
     ReadArrays lra{};           // rec_* only: raw sums per text line
     uint64_t cap_chunks = 0, cap_lines = 0;
+    int64_t fq_line_hint = -1;  // mean bytes per line of the last FASTQ text (-1: none yet); a hint for the scan pass only
 
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> ev_pool;
@@ -456,7 +457,7 @@ int ppqc_destroy(ppqc_ctx* c) {
     void* ptrs[] = {r.rec_cnt, r.rec_hi, r.rec_lo, r.len, r.gc, r.nn, r.qsum, r.mean_q, r.err_hi, r.err_lo, r.flags,
                     r.channel, r.mux, r.time, r.hour, r.lens32, c->head, c->tail, c->res_buf, c->sk32, c->sk32_tmp, c->counts, c->vals, c->vals_tmp, c->sk64,
                     c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev, c->dense.base, c->fq.counts, c->fq.n_entries, c->fq.entries, c->fq.prefix,
-                    c->fq.block_sums, c->fq.line_off, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo, c->m1};
+                    c->fq.block_sums, c->fq.line_off, c->fq.span_sum, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo, c->m1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->maxlen_host) (void)hipHostFree(c->maxlen_host);
@@ -642,6 +643,7 @@ int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
 
 // FASTQ text resident in device memory -> per-read arrays (see ppqc_fastq_gpu.hip).  One host synchronisation: the
 // number of lines has to be known to size the line table and the per-read arrays.
+constexpr int64_t kFastqSumsMinLine = 2048;   // mean bytes per line (headers and '+' lines included) from which the span sums pay
 static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, uint64_t* n_records) {
     if (n_records) *n_records = 0;
     if (n == 0) return PPQC_OK;
@@ -653,13 +655,24 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
         CHK(grow(&c->fq.entries, 0, cap * kNlEntriesPerChunk, s));
         CHK(grow(&c->fq.prefix, 0, cap + 2, s));
         CHK(grow(&c->fq.block_sums, 0, nl_scan_block_words(cap), s));
+        CHK(grow(&c->fq.span_sum, 0, cap * 2 * (kNlChunk / kSpan), s));
         c->cap_chunks = cap;
     }
     uint64_t* h = c->maxlen_host;   // pinned scratch words [1] = newlines, [2] = chunks with too many odd vectors, [3] = last byte
-    HIPCHK(launch_nl_scan(text, n, c->fq, h + 1, c->ev_fq, s));   // the scan's top kernel writes them
+    // Long lines: the scan pass also sums every clean 1 KiB span, and the lines are put together from those span sums
+    // instead of a second pass over the text (ppqc_fastq_gpu.hip).  It pays when the two end spans of a line are a small
+    // part of it; the scan has to be chosen before the line count is known, so the last text's mean line length decides
+    // (the first text of a context is taken to be long; a wrong guess costs the scan pass its extra arithmetic, nothing
+    // else).  PPQC_FASTQ_SUMS = 0 | 2: never / whenever the line ends fit the notes (A/B runs and tests).
+    const char* fs_env = getenv("PPQC_FASTQ_SUMS");
+    const int fs_mode = fs_env ? atoi(fs_env) : 1;
+    const bool with_sums = fs_mode == 2 || (fs_mode == 1 && (c->fq_line_hint < 0 || c->fq_line_hint >= kFastqSumsMinLine));
+    HIPCHK(launch_nl_scan(text, n, c->fq, h + 1, c->ev_fq, s, with_sums ? c->lut_dev : nullptr));   // the scan's top kernel writes them
     HIPCHK(hipEventSynchronize(c->ev_fq));
     const uint64_t n_lines = h[1] + (((uint8_t)h[3]) != '\n' ? 1 : 0);
     const bool sparse = h[2] == 0;
+    c->fq_line_hint = n_lines ? (int64_t)(n / n_lines) : -1;
+    const bool from_sums = with_sums && sparse && (fs_mode == 2 || c->fq_line_hint >= kFastqSumsMinLine);
     if (n_lines % 4 != 0)
         return fail(PPQC_E_INVALID, "FASTQ text has " + std::to_string(n_lines) + " lines, not a multiple of 4 (blank "
                                         "lines or multi-line records: use ppqc_fastq_scan / ppqc_fastq_pack)");
@@ -679,11 +692,15 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     // on the auxiliary stream (also at the highest stream priority) its blocks trickle in between the tile kernel's for
     // the whole 0.72 ms and fastq_finalize waits 50 us for the last of them.
     HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, s));
-    // line mode: both classifiers run over the same text, every line is a segment
-    BatchView v{text, text, c->fq.line_off, n_lines, n, nullptr, shift, nullptr, nullptr, nullptr};
-    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->dense, c->n_cu, s, true));
+    if (from_sums) {
+        HIPCHK(launch_line_sums(text, n, R, c->fq.line_off, c->fq.span_sum, c->lut_dev, c->lra, s));
+    } else {
+        // line mode: both classifiers run over the same text, every line is a segment
+        BatchView v{text, text, c->fq.line_off, n_lines, n, nullptr, shift, nullptr, nullptr, nullptr};
+        HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->dense, c->n_cu, s, true));
+    }
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
-                                 c->lut_dev, c->tp.thr_fail, c->tp.fail_q, mux, c->res_buf + c->res_words, s));
+                                 c->lut_dev, c->tp.thr_fail, c->tp.fail_q, mux, c->res_buf + c->res_words, s, from_sums));
     c->n_reads += R;
     c->state = 0;
     c->lens_early = false;   // lens32 of these reads is written by the extremes kernel

@@ -89,11 +89,30 @@ __device__ __forceinline__ uint4 load_vec_clamped(const uint8_t* __restrict__ te
 // the two passes.)
 constexpr int kNlEntries = (int)kNlEntriesPerChunk;
 
+// Span sums (SUMS): while the chunk's vectors are in registers anyway, every CLEAN 1 KiB span -- all of it inside the text
+// and every byte in '!'..'~', so it lies inside one line -- is also summed by ONE classifier, guessed from the bytes: the
+// base classifier when every byte is at or above '@' (a stretch of sequence), else the quality classifier.  The sums go
+// to span_sum[span] = {w0, w1}:
+//   w0 bit 63: the span has sums; bit 62: they are quality sums;
+//   bases:   w0 bits [0,16) G/C/S count, [16,32) N count
+//   quality: w0 bits [0,20) byte sum, w1 = fixed-point error sum (< 2^62)
+// line_sum_kernel then adds up the span sums inside each sequence and quality line and reads from the text only the spans
+// at a line's two ends and the (rare) spans whose guess was not the line's classifier: for long reads the text is read
+// ONCE plus a fifth.  A wrong guess costs time, never correctness.
+constexpr uint64_t kSpanHas = 1ull << 63, kSpanQual = 1ull << 62;
+
 // entry = vector index in the chunk (bits 32..41) | newline bits (0..15) | invalid-quality bits (16..31)
+template <bool SUMS>
 __global__ __launch_bounds__(256) void nl_scan_kernel(const uint8_t* __restrict__ text, uint64_t n,
                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ n_entries,
                                                       uint64_t* __restrict__ entries, uint64_t n_chunks,
-                                                      uint64_t* __restrict__ overflow) {
+                                                      uint64_t* __restrict__ overflow, uint64_t* __restrict__ span_sum,
+                                                      const uint64_t* __restrict__ lut_g) {
+    __shared__ uint64_t lut[SUMS ? 256 : 1];
+    if (SUMS) {
+        lut[threadIdx.x] = lut_g[threadIdx.x];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (chunk >= n_chunks) return;
@@ -105,13 +124,15 @@ __global__ __launch_bounds__(256) void nl_scan_kernel(const uint8_t* __restrict_
         vv[it] = load_vec_clamped(text, pos < n ? pos : 0, n);
     }
     uint32_t cnt = 0, ne = 0;   // ne: wave-uniform
+    uint64_t s0 = 0, s1 = 0;    // SUMS: lane `it` keeps the words of span `it`
 #pragma unroll
     for (int it = 0; it < kIt; ++it) {
         const uint64_t pos = chunk * kNlChunk + (uint64_t)it * kSpan + (uint64_t)lane * kVec;
         const uint4& v = vv[it];
         uint32_t bits = 0, bad = 0;
         // nearly every vector holds only '!'..'~' bytes: one cheap test, the exact masks only where it fires
-        if (pos < n && (odd_byte_mask(v.x) | odd_byte_mask(v.y) | odd_byte_mask(v.z) | odd_byte_mask(v.w))) {
+        const bool oddv = pos < n && (odd_byte_mask(v.x) | odd_byte_mask(v.y) | odd_byte_mask(v.z) | odd_byte_mask(v.w));
+        if (oddv) {
             const uint64_t rem = n - pos;
             bits = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
             bad = vec_badq_bits(v, rem < 16 ? (int)rem : 16);
@@ -124,6 +145,31 @@ __global__ __launch_bounds__(256) void nl_scan_kernel(const uint8_t* __restrict_
                 entries[chunk * kNlEntries + at] = ((uint64_t)(it * 64 + lane) << 32) | ((uint64_t)bad << 16) | bits;
             ne += (uint32_t)__popcll(odd);
         }
+        if (SUMS) {
+            const bool whole = chunk * kNlChunk + (uint64_t)(it + 1) * kSpan <= n;   // wave-uniform
+            uint64_t w0 = 0, w1 = 0;
+            if (whole && __ballot(oddv) == 0) {
+                const bool low = ((v.x & v.y & v.z & v.w) & 0x40404040u) != 0x40404040u;   // a byte below '@'
+                if (__ballot(low) == 0) {
+                    const Acc a = vec_sums_bases(v);
+                    const uint32_t P = wave_sum_u32(a.gcs | (a.n << 16));   // at most 1024 each
+                    w0 = kSpanHas | P;
+                } else {
+                    const Acc a = vec_sums_quals(v, lut);
+                    // per lane: byte sum <= 4080, error sum < 2^56, in pieces whose wave sums fit 32 bits
+                    const uint32_t P0 = wave_sum_u32((uint32_t)a.err & 0x3FFFFFFu);
+                    const uint32_t P1 = wave_sum_u32((uint32_t)(a.err >> 26) & 0x3FFFFFFu);
+                    const uint32_t P2 = wave_sum_u32((uint32_t)(a.err >> 52) | (a.qb << 10));
+                    w0 = kSpanHas | kSpanQual | (uint64_t)(P2 >> 10);
+                    w1 = (uint64_t)P0 + ((uint64_t)P1 << 26) + ((uint64_t)(P2 & 0x3FFu) << 52);
+                }
+            }
+            if (lane == it) { s0 = w0; s1 = w1; }
+        }
+    }
+    if (SUMS && lane < kIt) {
+        uint64_t* o = span_sum + 2 * (chunk * kIt + (uint64_t)lane);
+        o[0] = s0; o[1] = s1;
     }
     cnt = wave_sum_u32(cnt);
     if (lane == 0) {
@@ -323,12 +369,17 @@ __global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict_
 // Pass 1 and the scan: counts, entries and the chunks' line numbers; fs.prefix[n_chunks] = newlines of the text,
 // fs.prefix[n_chunks + 1] = chunks whose entry list overflowed.
 hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, uint64_t* host_out, hipEvent_t counted,
-                          hipStream_t s) {
+                          hipStream_t s, const uint64_t* lut_dev) {
     const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
     hipError_t e = hipMemsetAsync(fs.prefix + n_chunks, 0, 16, s);
     if (e != hipSuccess || n_chunks == 0) return e;
-    hipLaunchKernelGGL(nl_scan_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, text, n, fs.counts, fs.n_entries,
-                       fs.entries, n_chunks, fs.prefix + n_chunks + 1);
+    if (lut_dev)   // with span sums (fs.span_sum holds two words per 1 KiB span of every chunk)
+        hipLaunchKernelGGL(nl_scan_kernel<true>, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, text, n, fs.counts,
+                           fs.n_entries, fs.entries, n_chunks, fs.prefix + n_chunks + 1, fs.span_sum, lut_dev);
+    else
+        hipLaunchKernelGGL(nl_scan_kernel<false>, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, text, n, fs.counts,
+                           fs.n_entries, fs.entries, n_chunks, fs.prefix + n_chunks + 1, (uint64_t*)nullptr,
+                           (const uint64_t*)nullptr);
     const uint64_t nblocks = (n_chunks + kScanBlock - 1) / kScanBlock;
     hipLaunchKernelGGL(nl_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, fs.counts, n_chunks, fs.block_sums);
     hipLaunchKernelGGL(nl_scan_top_kernel, dim3(1), dim3(256), 0, s, fs.block_sums, nblocks, fs.prefix + n_chunks, host_out,
@@ -461,6 +512,97 @@ __global__ __launch_bounds__(256) void fastq_header_kernel(const uint8_t* __rest
     ra.time[g] = h.time();
 }
 
+// ---- line sums from the span sums of the scan pass ------------------------------------------------------------------------
+// Per-lane sums of the bytes of span k (1 KiB at text + k * kSpan) that lie in [a, e), by one classifier.  Bytes outside
+// are zeroed: a zero byte matches no base class and adds nothing to the byte sum, and its LUT entry (2^52) is taken off.
+template <bool QUAL>
+__device__ __forceinline__ void direct_span(const uint8_t* __restrict__ text, uint64_t n, uint64_t k, uint64_t a, uint64_t e,
+                                            const uint64_t* lut, int lane, uint64_t& c0, uint64_t& c1, uint64_t& hi,
+                                            uint64_t& lw) {
+    const uint64_t pos = k * kSpan + (uint64_t)lane * kVec;
+    const uint64_t b0 = a > pos ? a : pos, b1 = e < pos + kVec ? e : pos + kVec;
+    if (b1 <= b0) return;
+    const uint4 v = load_vec_clamped(text, pos, n);   // pos < e <= n
+    const int x0 = (int)(b0 - pos), x1 = (int)(b1 - pos);
+    uint32_t m[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        int l = x0 - 4 * w, h = x1 - 4 * w;
+        l = l < 0 ? 0 : (l > 4 ? 4 : l);
+        h = h < 0 ? 0 : (h > 4 ? 4 : h);
+        m[w] = (uint32_t)(((1ull << (8 * h)) - 1ull) & ~((1ull << (8 * l)) - 1ull));
+    }
+    const uint4 mv = make_uint4(v.x & m[0], v.y & m[1], v.z & m[2], v.w & m[3]);
+    if (QUAL) {
+        const Acc q = vec_sums_quals(mv, lut);
+        const uint64_t err = q.err - ((uint64_t)(kVec - (x1 - x0)) << PPQC_ERR_SHIFT);
+        c0 += q.qb; hi += err >> 32; lw += err & 0xffffffffull;
+    } else {
+        const Acc b = vec_sums_bases(mv);
+        c0 += b.gcs; c1 += b.n;
+    }
+}
+
+// One line [a, e) (its line end included, as in the line-mode tile kernel: fastq_finalize takes off what the stripped end
+// added): the spans at its two ends from the text, the spans in between from their span sums -- or from the text where a
+// span has none or the other classifier's.  Sequence line: rec_cnt = G/C/S count, rec_hi = N count; quality line:
+// rec_cnt = byte sum, rec_hi / rec_lo = the halves of the error sum (S = hi * 2^32 + lo, as everywhere).
+template <bool QUAL>
+__device__ __forceinline__ void one_line(const uint8_t* __restrict__ text, uint64_t n, uint64_t line, uint64_t a, uint64_t e,
+                                         const uint64_t* __restrict__ span_sum, const uint64_t* lut, int lane,
+                                         const ReadArrays& lra) {
+    uint64_t c0 = 0, c1 = 0, hi = 0, lw = 0;
+    if (e > a) {
+        const uint64_t k0 = a / kSpan, k1 = (e - 1) / kSpan;
+        direct_span<QUAL>(text, n, k0, a, e, lut, lane, c0, c1, hi, lw);
+        if (k1 != k0) direct_span<QUAL>(text, n, k1, a, e, lut, lane, c0, c1, hi, lw);
+        for (uint64_t kb = k0 + 1; kb < k1; kb += 64) {   // wave-uniform
+            const uint64_t k = kb + (uint64_t)lane;
+            const bool in = k < k1;
+            uint64_t w0 = 0, w1 = 0;
+            if (in) {
+                const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(span_sum + 2 * k);
+                w0 = w.x; w1 = w.y;
+            }
+            const bool ok = in && (w0 & kSpanHas) && (((w0 & kSpanQual) != 0) == QUAL);
+            if (ok) {
+                if (QUAL) { c0 += w0 & 0xFFFFFull; hi += w1 >> 32; lw += w1 & 0xffffffffull; }
+                else { c0 += w0 & 0xFFFFull; c1 += (w0 >> 16) & 0xFFFFull; }
+            }
+            uint64_t bad = __ballot(in && !ok);
+            while (bad) {
+                const int b = __builtin_ctzll(bad);
+                bad &= bad - 1;
+                direct_span<QUAL>(text, n, kb + (uint64_t)b, a, e, lut, lane, c0, c1, hi, lw);
+            }
+        }
+    }
+    c0 = wave_sum_u64(c0);
+    if (QUAL) { hi = wave_sum_u64(hi); lw = wave_sum_u64(lw); } else { c1 = wave_sum_u64(c1); }
+    if (lane == 0) {
+        lra.rec_cnt[line] = c0;
+        lra.rec_hi[line] = QUAL ? hi : c1;
+        lra.rec_lo[line] = QUAL ? lw : 0;
+    }
+}
+
+// one wave per record: its sequence line and its quality line
+__global__ __launch_bounds__(256) void line_sum_kernel(const uint8_t* __restrict__ text, uint64_t n, uint64_t n_records,
+                                                       const uint64_t* __restrict__ lo, const uint64_t* __restrict__ span_sum,
+                                                       const uint64_t* __restrict__ lut_g, ReadArrays lra) {
+    __shared__ uint64_t lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_records) return;
+    const uint64_t a1 = uniform_u64(lo[4 * r + 1]), e1 = uniform_u64(lo[4 * r + 2]);
+    const uint64_t a3 = uniform_u64(lo[4 * r + 3]), e3 = uniform_u64(lo[4 * r + 4]);
+    one_line<false>(text, n, 4 * r + 1, a1, e1, span_sum, lut, lane, lra);
+    one_line<true>(text, n, 4 * r + 3, a3, e3, span_sum, lut, lane, lra);
+}
+
+template <bool WHOLE>
 __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __restrict__ text, uint64_t n,
                                                              uint64_t n_records, const uint64_t* __restrict__ lo,
                                                              ReadArrays lra, ReadArrays ra, uint64_t read_base,
@@ -494,8 +636,14 @@ __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __re
         atomicMin((unsigned long long*)&errors[2], (unsigned long long)r);
     } else if (L != 0) {
         const uint64_t s1 = lo[4 * r + 1], f1 = lo[4 * r + 2], s3 = lo[4 * r + 3], f3 = lo[4 * r + 4];
-        const SegSums b = merged_sums(s1, f1, 4 * r + 1, lra, head, tail, tile_shift);
-        const SegSums q = merged_sums(s3, f3, 4 * r + 3, lra, head, tail, tile_shift);
+        SegSums b, q;
+        if (WHOLE) {   // line_sum_kernel has left whole lines
+            b.gcs = lra.rec_cnt[4 * r + 1]; b.nn = lra.rec_hi[4 * r + 1];
+            q.qb = lra.rec_cnt[4 * r + 3]; q.hi = lra.rec_hi[4 * r + 3]; q.lo = lra.rec_lo[4 * r + 3];
+        } else {
+            b = merged_sums(s1, f1, 4 * r + 1, lra, head, tail, tile_shift);
+            q = merged_sums(s3, f3, 4 * r + 3, lra, head, tail, tile_shift);
+        }
         gcs = b.gcs; nn = b.nn;
         qb = q.qb - strip_qb;
         // S = hi * 2^32 + lo with halves that are sums; subtract the stripped bytes from the combined value
@@ -535,11 +683,24 @@ hipError_t launch_fastq_header(const uint8_t* text, uint64_t n_records, const ui
 hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
                                  ReadArrays line_ra, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint32_t tile_shift, const uint64_t* lut, uint64_t thr_fail,
-                                 double fail_q, uint8_t mux, uint64_t* errors, hipStream_t s) {
+                                 double fail_q, uint8_t mux, uint64_t* errors, hipStream_t s, bool whole_lines) {
     if (n_records == 0) return hipSuccess;
-    hipLaunchKernelGGL(fastq_finalize_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n,
-                       n_records, line_off, line_ra, ra, read_base, head, tail, tile_shift, lut, thr_fail, fail_q, mux,
-                       errors);
+    if (whole_lines)
+        hipLaunchKernelGGL(fastq_finalize_kernel<true>, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n,
+                           n_records, line_off, line_ra, ra, read_base, head, tail, tile_shift, lut, thr_fail, fail_q, mux,
+                           errors);
+    else
+        hipLaunchKernelGGL(fastq_finalize_kernel<false>, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n,
+                           n_records, line_off, line_ra, ra, read_base, head, tail, tile_shift, lut, thr_fail, fail_q, mux,
+                           errors);
+    return hipGetLastError();
+}
+
+hipError_t launch_line_sums(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
+                            const uint64_t* span_sum, const uint64_t* lut_dev, ReadArrays line_ra, hipStream_t s) {
+    if (n_records == 0) return hipSuccess;
+    hipLaunchKernelGGL(line_sum_kernel, dim3((unsigned)((n_records + 3) / 4)), dim3(256), 0, s, text, n, n_records, line_off,
+                       span_sum, lut_dev, line_ra);
     return hipGetLastError();
 }
 

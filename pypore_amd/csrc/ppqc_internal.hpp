@@ -160,10 +160,15 @@ struct FastqScratch {
     uint64_t* prefix;       // exclusive prefix of counts; [n_chunks] = newlines of the text, [n_chunks + 1] = overflowing chunks
     uint64_t* block_sums;   // scan scratch
     uint64_t* line_off;     // n_lines + 1 line starts (the CSR offsets of the line-mode tile kernel)
+    uint64_t* span_sum;     // two words per 1 KiB span of every chunk: the scan pass's span sums (ppqc_fastq_gpu.hip)
 };
 uint64_t nl_scan_block_words(uint64_t n_chunks);
+// lut_dev != nullptr: the pass also leaves the span sums in fs.span_sum
 hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, uint64_t* host_out, hipEvent_t counted,
-                          hipStream_t s);
+                          hipStream_t s, const uint64_t* lut_dev = nullptr);
+// whole lines from the span sums (sequence and quality line of every record) into line_ra.rec_*
+hipError_t launch_line_sums(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
+                            const uint64_t* span_sum, const uint64_t* lut_dev, ReadArrays line_ra, hipStream_t s);
 hipError_t launch_nl_place(const uint8_t* text, uint64_t n, uint64_t n_lines, bool sparse, const FastqScratch& fs,
                            uint64_t* errors, hipStream_t s);
 // one thread per record: validates the four lines, strips line ends, merges the line sums into the per-read arrays,
@@ -174,7 +179,7 @@ hipError_t launch_fastq_header(const uint8_t* text, uint64_t n_records, const ui
 hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
                                  ReadArrays line_ra, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint32_t tile_shift, const uint64_t* lut, uint64_t thr_fail,
-                                 double fail_q, uint8_t mux, uint64_t* errors, hipStream_t s);
+                                 double fail_q, uint8_t mux, uint64_t* errors, hipStream_t s, bool whole_lines = false);
 
 hipError_t launch_synth(uint8_t* bases, uint8_t* quals, uint64_t first, uint64_t n, uint64_t seed, hipStream_t s);
 
@@ -263,6 +268,68 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
     uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
     uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
+}
+
+// ---- byte classification shared by the per-read kernels and the FASTQ text kernels ------------------------------
+struct Acc {
+    uint32_t gcs, n, qb;
+    uint64_t err;
+};
+
+// G/C/S (either case) and N (either case) byte counts of a 4-byte word, exact for arbitrary bytes.
+// lo drops the case bit and the high bit, so every byte is <= 0x5F; (lo ^ K) + 0x7F has its byte's high bit clear
+// iff the byte equals K (no inter-byte carries since lo ^ K <= 0x7F).  Bytes with the high bit set never match (h).
+__device__ __forceinline__ void bases_word(uint32_t v, uint32_t& gcs, uint32_t& n) {
+    const uint32_t h = v & 0x80808080u;
+    const uint32_t lo = v & 0x5F5F5F5Fu;
+    const uint32_t tGC = ((lo & 0x5B5B5B5Bu) ^ 0x43434343u) + 0x7F7F7F7Fu;   // C = 0x43, G = 0x47 differ in bit 2
+    const uint32_t tS = (lo ^ 0x53535353u) + 0x7F7F7F7Fu;
+    const uint32_t tN = (lo ^ 0x4E4E4E4Eu) + 0x7F7F7F7Fu;
+    gcs += __popc(~((tGC & tS) | h) & 0x80808080u);
+    n += __popc(~(tN | h) & 0x80808080u);
+}
+
+__device__ __forceinline__ void quals_word(uint32_t w, const uint64_t* lut, uint32_t& qb, uint64_t& err) {
+    qb = __builtin_amdgcn_sad_u8(w, 0u, qb);
+    err += lut[w & 0xffu];
+    err += lut[(w >> 8) & 0xffu];
+    err += lut[(w >> 16) & 0xffu];
+    err += lut[w >> 24];
+}
+
+__device__ __forceinline__ Acc vec_sums(const uint4& vb, const uint4& vq, const uint64_t* lut) {
+    Acc a{0, 0, 0, 0};
+    bases_word(vb.x, a.gcs, a.n);
+    bases_word(vb.y, a.gcs, a.n);
+    bases_word(vb.z, a.gcs, a.n);
+    bases_word(vb.w, a.gcs, a.n);
+    uint64_t e0 = 0, e1 = 0;
+    quals_word(vq.x, lut, a.qb, e0);
+    quals_word(vq.y, lut, a.qb, e1);
+    quals_word(vq.z, lut, a.qb, e0);
+    quals_word(vq.w, lut, a.qb, e1);
+    a.err = e0 + e1;
+    return a;
+}
+
+// Line mode (FASTQ text, bases == quals == text): a span inside one line needs only that line's classifier.
+__device__ __forceinline__ Acc vec_sums_bases(const uint4& vb) {
+    Acc a{0, 0, 0, 0};
+    bases_word(vb.x, a.gcs, a.n);
+    bases_word(vb.y, a.gcs, a.n);
+    bases_word(vb.z, a.gcs, a.n);
+    bases_word(vb.w, a.gcs, a.n);
+    return a;
+}
+__device__ __forceinline__ Acc vec_sums_quals(const uint4& vq, const uint64_t* lut) {
+    Acc a{0, 0, 0, 0};
+    uint64_t e0 = 0, e1 = 0;
+    quals_word(vq.x, lut, a.qb, e0);
+    quals_word(vq.y, lut, a.qb, e1);
+    quals_word(vq.z, lut, a.qb, e0);
+    quals_word(vq.w, lut, a.qb, e1);
+    a.err = e0 + e1;
+    return a;
 }
 #endif
 

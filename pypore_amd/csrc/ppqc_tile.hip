@@ -23,67 +23,6 @@ namespace ppqc {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-struct Acc {
-    uint32_t gcs, n, qb;
-    uint64_t err;
-};
-
-// G/C/S (either case) and N (either case) byte counts of a 4-byte word, exact for arbitrary bytes.
-// lo drops the case bit and the high bit, so every byte is <= 0x5F; (lo ^ K) + 0x7F has its byte's high bit clear
-// iff the byte equals K (no inter-byte carries since lo ^ K <= 0x7F).  Bytes with the high bit set never match (h).
-__device__ __forceinline__ void bases_word(uint32_t v, uint32_t& gcs, uint32_t& n) {
-    const uint32_t h = v & 0x80808080u;
-    const uint32_t lo = v & 0x5F5F5F5Fu;
-    const uint32_t tGC = ((lo & 0x5B5B5B5Bu) ^ 0x43434343u) + 0x7F7F7F7Fu;   // C = 0x43, G = 0x47 differ in bit 2
-    const uint32_t tS = (lo ^ 0x53535353u) + 0x7F7F7F7Fu;
-    const uint32_t tN = (lo ^ 0x4E4E4E4Eu) + 0x7F7F7F7Fu;
-    gcs += __popc(~((tGC & tS) | h) & 0x80808080u);
-    n += __popc(~(tN | h) & 0x80808080u);
-}
-
-__device__ __forceinline__ void quals_word(uint32_t w, const uint64_t* lut, uint32_t& qb, uint64_t& err) {
-    qb = __builtin_amdgcn_sad_u8(w, 0u, qb);
-    err += lut[w & 0xffu];
-    err += lut[(w >> 8) & 0xffu];
-    err += lut[(w >> 16) & 0xffu];
-    err += lut[w >> 24];
-}
-
-__device__ __forceinline__ Acc vec_sums(const uint4& vb, const uint4& vq, const uint64_t* lut) {
-    Acc a{0, 0, 0, 0};
-    bases_word(vb.x, a.gcs, a.n);
-    bases_word(vb.y, a.gcs, a.n);
-    bases_word(vb.z, a.gcs, a.n);
-    bases_word(vb.w, a.gcs, a.n);
-    uint64_t e0 = 0, e1 = 0;
-    quals_word(vq.x, lut, a.qb, e0);
-    quals_word(vq.y, lut, a.qb, e1);
-    quals_word(vq.z, lut, a.qb, e0);
-    quals_word(vq.w, lut, a.qb, e1);
-    a.err = e0 + e1;
-    return a;
-}
-
-// Line mode (FASTQ text, bases == quals == text): a span inside one line needs only that line's classifier.
-__device__ __forceinline__ Acc vec_sums_bases(const uint4& vb) {
-    Acc a{0, 0, 0, 0};
-    bases_word(vb.x, a.gcs, a.n);
-    bases_word(vb.y, a.gcs, a.n);
-    bases_word(vb.z, a.gcs, a.n);
-    bases_word(vb.w, a.gcs, a.n);
-    return a;
-}
-__device__ __forceinline__ Acc vec_sums_quals(const uint4& vq, const uint64_t* lut) {
-    Acc a{0, 0, 0, 0};
-    uint64_t e0 = 0, e1 = 0;
-    quals_word(vq.x, lut, a.qb, e0);
-    quals_word(vq.y, lut, a.qb, e1);
-    quals_word(vq.z, lut, a.qb, e0);
-    quals_word(vq.w, lut, a.qb, e1);
-    a.err = e0 + e1;
-    return a;
-}
-
 // Sums over the first x (0..16) bytes of the lane's vectors (VECB kernels): the bytes from x on are zeroed (a zero byte
 // matches no base class and adds nothing to the byte sum) and their LUT entries, lut[0] = 2^52 each, are taken off again.
 __device__ __noinline__ Acc vec_prefix(uint4 vb, uint4 vq, int x, const uint64_t* lut) {

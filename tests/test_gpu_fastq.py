@@ -13,6 +13,15 @@ CFG = dict(n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=
 ALPH = np.frombuffer(b"ACGTACGTNnacgtSs", np.uint8)
 
 
+@pytest.fixture(autouse=True, params=["0", "2"], ids=["second_pass", "span_sums"])
+def line_sums_from(request, monkeypatch):
+    """Every test runs both ways the line sums are made: the line-mode tile kernel's second pass over the text
+    (PPQC_FASTQ_SUMS=0) and the span sums of the scan pass put together per line (2: whenever the notes hold every line
+    end; by default the library takes them for long lines only).  The library reads the variable at every submit."""
+    monkeypatch.setenv("PPQC_FASTQ_SUMS", request.param)
+    return request.param
+
+
 def _text(seed, n, crlf=False, trailing=True, plus_title=False, lens=None, fields=True):
     rng = np.random.default_rng(seed)
     nl = b"\r\n" if crlf else b"\n"
