@@ -158,6 +158,7 @@ struct ppqc_ctx {
     bool n50_early = false; // ppqc_n50_select_early has left the N50 of the run's reads (no batch since)
     hipEvent_t ev_pre = nullptr;   // behind the newest of those kernels (auxiliary stream)
     hipEvent_t ev_fq = nullptr;    // FASTQ text: the newlines are counted (the host waits for it)
+    hipEvent_t ev_hdr = nullptr;   // FASTQ text: behind the header kernel when it runs on the auxiliary stream
     hipEvent_t ev_clean = nullptr; // behind the clear of the result buffer (ppqc_reset / ppqc_create, main stream)
     uint64_t* maxlen_host = nullptr;   // a few pinned scratch words (line count of the GPU tokenizer)
     uint64_t* m1 = nullptr;            // time_mode 1 across ranks: [first | ties | days] (ppqc_mode1_dist_view)
@@ -367,6 +368,7 @@ static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_clean, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fq, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_hdr, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->ev_join));
     HIPCHK(hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
@@ -465,6 +467,7 @@ int ppqc_destroy(ppqc_ctx* c) {
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     if (c->ev_clean) (void)hipEventDestroy(c->ev_clean);
     if (c->ev_fq) (void)hipEventDestroy(c->ev_fq);
+    if (c->ev_hdr) (void)hipEventDestroy(c->ev_hdr);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_reads) (void)hipEventDestroy(c->ev_reads);
@@ -691,9 +694,20 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     // The headers need the line table only.  Their kernel runs in front of the tile kernel on the same stream: beside it
     // on the auxiliary stream (also at the highest stream priority) its blocks trickle in between the tile kernel's for
     // the whole 0.72 ms and fastq_finalize waits 50 us for the last of them.
-    HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, s));
+    // ... line_sum_kernel is short and leaves room: beside it the header kernel is hidden (1.29 -> 1.265 ms for the step;
+    // PPQC_FASTQ_HDR_AUX = 0 puts it back in front)
+    const bool hdr_aux = from_sums && !(getenv("PPQC_FASTQ_HDR_AUX") && atoi(getenv("PPQC_FASTQ_HDR_AUX")) == 0);
+    if (hdr_aux) {
+        HIPCHK(hipEventRecord(c->ev_fq, s));
+        HIPCHK(hipStreamWaitEvent(c->aux, c->ev_fq, 0));
+        HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, c->aux));
+        HIPCHK(hipEventRecord(c->ev_hdr, c->aux));
+    } else {
+        HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, s));
+    }
     if (from_sums) {
         HIPCHK(launch_line_sums(text, n, R, c->fq.line_off, c->fq.span_sum, c->lut_dev, c->lra, s));
+        if (hdr_aux) HIPCHK(hipStreamWaitEvent(s, c->ev_hdr, 0));
     } else {
         // line mode: both classifiers run over the same text, every line is a segment
         BatchView v{text, text, c->fq.line_off, n_lines, n, nullptr, shift, nullptr, nullptr, nullptr};

@@ -515,6 +515,17 @@ __global__ __launch_bounds__(256) void fastq_header_kernel(const uint8_t* __rest
 // ---- line sums from the span sums of the scan pass ------------------------------------------------------------------------
 // Per-lane sums of the bytes of span k (1 KiB at text + k * kSpan) that lie in [a, e), by one classifier.  Bytes outside
 // are zeroed: a zero byte matches no base class and adds nothing to the byte sum, and its LUT entry (2^52) is taken off.
+// m[w]: the bytes of word w of a 16-byte vector that lie in [x0, x1), 0 <= x0 < x1 <= 16 (32-bit shifts only)
+__device__ __forceinline__ void range_masks(int x0, int x1, uint32_t m[4]) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int l = x0 - 4 * w, h = x1 - 4 * w;
+        const uint32_t below_h = h >= 4 ? 0xFFFFFFFFu : (h <= 0 ? 0u : (1u << (8 * h)) - 1u);
+        const uint32_t below_l = l >= 4 ? 0xFFFFFFFFu : (l <= 0 ? 0u : (1u << (8 * l)) - 1u);
+        m[w] = below_h & ~below_l;
+    }
+}
+
 template <bool QUAL>
 __device__ __forceinline__ void direct_span(const uint8_t* __restrict__ text, uint64_t n, uint64_t k, uint64_t a, uint64_t e,
                                             const uint64_t* lut, int lane, uint64_t& c0, uint64_t& c1, uint64_t& hi,
@@ -525,13 +536,7 @@ __device__ __forceinline__ void direct_span(const uint8_t* __restrict__ text, ui
     const uint4 v = load_vec_clamped(text, pos, n);   // pos < e <= n
     const int x0 = (int)(b0 - pos), x1 = (int)(b1 - pos);
     uint32_t m[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        int l = x0 - 4 * w, h = x1 - 4 * w;
-        l = l < 0 ? 0 : (l > 4 ? 4 : l);
-        h = h < 0 ? 0 : (h > 4 ? 4 : h);
-        m[w] = (uint32_t)(((1ull << (8 * h)) - 1ull) & ~((1ull << (8 * l)) - 1ull));
-    }
+    range_masks(x0, x1, m);
     const uint4 mv = make_uint4(v.x & m[0], v.y & m[1], v.z & m[2], v.w & m[3]);
     if (QUAL) {
         const Acc q = vec_sums_quals(mv, lut);
@@ -547,42 +552,95 @@ __device__ __forceinline__ void direct_span(const uint8_t* __restrict__ text, ui
 // added): the spans at its two ends from the text, the spans in between from their span sums -- or from the text where a
 // span has none or the other classifier's.  Sequence line: rec_cnt = G/C/S count, rec_hi = N count; quality line:
 // rec_cnt = byte sum, rec_hi / rec_lo = the halves of the error sum (S = hi * 2^32 + lo, as everywhere).
+// In two steps, so that a wave has the loads of both its lines in flight before it looks at any of them (the kernel is a
+// chain of memory latencies: line table -> end spans and span sums -> record; 215 us for 200 000 records when the lines
+// were taken one after the other, load by load).
+struct LineJob {
+    uint64_t a, e, k0, k1;   // k0, k1: first and last span of the line
+    uint4 v0, v1;            // the lane's vectors of those two spans
+    uint64_t w0, w1;         // span sums of span k0 + 1 + lane
+    bool in;
+};
+__device__ __forceinline__ void line_begin(LineJob& j, const uint8_t* __restrict__ text, uint64_t n, uint64_t a, uint64_t e,
+                                           const uint64_t* __restrict__ span_sum, int lane) {
+    j.a = a; j.e = e; j.k0 = 0; j.k1 = 0; j.in = false; j.w0 = j.w1 = 0;
+    j.v0 = j.v1 = make_uint4(0, 0, 0, 0);
+    if (e <= a) return;   // wave-uniform
+    j.k0 = a / kSpan; j.k1 = (e - 1) / kSpan;
+    const uint64_t p0 = j.k0 * kSpan + (uint64_t)lane * kVec, p1 = j.k1 * kSpan + (uint64_t)lane * kVec;
+    if (p0 + kVec > a && p0 < e) j.v0 = load_vec_clamped(text, p0, n);
+    if (j.k1 != j.k0 && p1 < e) j.v1 = load_vec_clamped(text, p1, n);
+    const uint64_t k = j.k0 + 1 + (uint64_t)lane;
+    j.in = k < j.k1;
+    if (j.in) {
+        const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(span_sum + 2 * k);
+        j.w0 = w.x; j.w1 = w.y;
+    }
+}
+
+// the lane's part of span k of the line, from the vector it has loaded
 template <bool QUAL>
-__device__ __forceinline__ void one_line(const uint8_t* __restrict__ text, uint64_t n, uint64_t line, uint64_t a, uint64_t e,
-                                         const uint64_t* __restrict__ span_sum, const uint64_t* lut, int lane,
-                                         const ReadArrays& lra) {
+__device__ __forceinline__ void edge_sum(const uint4& v, uint64_t k, uint64_t a, uint64_t e, const uint64_t* lut, int lane,
+                                         uint64_t& c0, uint64_t& c1, uint64_t& hi, uint64_t& lw) {
+    const uint64_t pos = k * kSpan + (uint64_t)lane * kVec;
+    const uint64_t b0 = a > pos ? a : pos, b1 = e < pos + kVec ? e : pos + kVec;
+    if (b1 <= b0) return;
+    const int x0 = (int)(b0 - pos), x1 = (int)(b1 - pos);
+    uint32_t m[4];
+    range_masks(x0, x1, m);
+    const uint4 mv = make_uint4(v.x & m[0], v.y & m[1], v.z & m[2], v.w & m[3]);
+    if (QUAL) {
+        const Acc q = vec_sums_quals(mv, lut);
+        const uint64_t err = q.err - ((uint64_t)(kVec - (x1 - x0)) << PPQC_ERR_SHIFT);
+        c0 += q.qb; hi += err >> 32; lw += err & 0xffffffffull;
+    } else {
+        const Acc b = vec_sums_bases(mv);
+        c0 += b.gcs; c1 += b.n;
+    }
+}
+
+template <bool QUAL>
+__device__ __forceinline__ void line_finish(LineJob& j, const uint8_t* __restrict__ text, uint64_t n, uint64_t line,
+                                            const uint64_t* __restrict__ span_sum, const uint64_t* lut, int lane,
+                                            const ReadArrays& lra) {
     uint64_t c0 = 0, c1 = 0, hi = 0, lw = 0;
-    if (e > a) {
-        const uint64_t k0 = a / kSpan, k1 = (e - 1) / kSpan;
-        direct_span<QUAL>(text, n, k0, a, e, lut, lane, c0, c1, hi, lw);
-        if (k1 != k0) direct_span<QUAL>(text, n, k1, a, e, lut, lane, c0, c1, hi, lw);
-        for (uint64_t kb = k0 + 1; kb < k1; kb += 64) {   // wave-uniform
-            const uint64_t k = kb + (uint64_t)lane;
-            const bool in = k < k1;
-            uint64_t w0 = 0, w1 = 0;
-            if (in) {
-                const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(span_sum + 2 * k);
-                w0 = w.x; w1 = w.y;
+    if (j.e > j.a) {
+        edge_sum<QUAL>(j.v0, j.k0, j.a, j.e, lut, lane, c0, c1, hi, lw);
+        if (j.k1 != j.k0) edge_sum<QUAL>(j.v1, j.k1, j.a, j.e, lut, lane, c0, c1, hi, lw);
+        for (uint64_t kb = j.k0 + 1; kb < j.k1; kb += 64) {   // wave-uniform; the first round's span sums are loaded
+            if (kb != j.k0 + 1) {
+                const uint64_t k = kb + (uint64_t)lane;
+                j.in = k < j.k1;
+                j.w0 = j.w1 = 0;
+                if (j.in) {
+                    const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(span_sum + 2 * k);
+                    j.w0 = w.x; j.w1 = w.y;
+                }
             }
-            const bool ok = in && (w0 & kSpanHas) && (((w0 & kSpanQual) != 0) == QUAL);
+            const bool ok = j.in && (j.w0 & kSpanHas) && (((j.w0 & kSpanQual) != 0) == QUAL);
             if (ok) {
-                if (QUAL) { c0 += w0 & 0xFFFFFull; hi += w1 >> 32; lw += w1 & 0xffffffffull; }
-                else { c0 += w0 & 0xFFFFull; c1 += (w0 >> 16) & 0xFFFFull; }
+                if (QUAL) { c0 += j.w0 & 0xFFFFFull; hi += j.w1 >> 32; lw += j.w1 & 0xffffffffull; }
+                else { c0 += j.w0 & 0xFFFFull; c1 += (j.w0 >> 16) & 0xFFFFull; }
             }
-            uint64_t bad = __ballot(in && !ok);
+            uint64_t bad = __ballot(j.in && !ok);
             while (bad) {
                 const int b = __builtin_ctzll(bad);
                 bad &= bad - 1;
-                direct_span<QUAL>(text, n, kb + (uint64_t)b, a, e, lut, lane, c0, c1, hi, lw);
+                direct_span<QUAL>(text, n, kb + (uint64_t)b, j.a, j.e, lut, lane, c0, c1, hi, lw);
             }
         }
     }
-    c0 = wave_sum_u64(c0);
-    if (QUAL) { hi = wave_sum_u64(hi); lw = wave_sum_u64(lw); } else { c1 = wave_sum_u64(c1); }
-    if (lane == 0) {
-        lra.rec_cnt[line] = c0;
-        lra.rec_hi[line] = QUAL ? hi : c1;
-        lra.rec_lo[line] = QUAL ? lw : 0;
+    // u32 wave sums (seven instructions each, four times that for a u64).  A line is shorter than 2^32 bytes, so its
+    // counts fit; per lane the byte sum stays below 2^35 and the halves of the error sum below 2^48 (2^16 span sums of
+    // 2^18, 2^30 and 2^32 at most), which go in pieces of 24 bits whose wave sums fit.
+    if (QUAL) {
+        const uint64_t C = (uint64_t)wave_sum_u32((uint32_t)c0 & 0xFFFFFFu) + ((uint64_t)wave_sum_u32((uint32_t)(c0 >> 24)) << 24);
+        const uint64_t H = (uint64_t)wave_sum_u32((uint32_t)hi & 0xFFFFFFu) + ((uint64_t)wave_sum_u32((uint32_t)(hi >> 24)) << 24);
+        const uint64_t L = (uint64_t)wave_sum_u32((uint32_t)lw & 0xFFFFFFu) + ((uint64_t)wave_sum_u32((uint32_t)(lw >> 24)) << 24);
+        if (lane == 0) { lra.rec_cnt[line] = C; lra.rec_hi[line] = H; lra.rec_lo[line] = L; }
+    } else {
+        const uint32_t G = wave_sum_u32((uint32_t)c0), N = wave_sum_u32((uint32_t)c1);
+        if (lane == 0) { lra.rec_cnt[line] = G; lra.rec_hi[line] = N; lra.rec_lo[line] = 0; }
     }
 }
 
@@ -596,10 +654,14 @@ __global__ __launch_bounds__(256) void line_sum_kernel(const uint8_t* __restrict
     const int lane = threadIdx.x & 63;
     const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_records) return;
-    const uint64_t a1 = uniform_u64(lo[4 * r + 1]), e1 = uniform_u64(lo[4 * r + 2]);
-    const uint64_t a3 = uniform_u64(lo[4 * r + 3]), e3 = uniform_u64(lo[4 * r + 4]);
-    one_line<false>(text, n, 4 * r + 1, a1, e1, span_sum, lut, lane, lra);
-    one_line<true>(text, n, 4 * r + 3, a3, e3, span_sum, lut, lane, lra);
+    // lines 4r + 1 .. 4r + 4 start at lo[4r + 1 ..]: one load, lanes 0..3
+    const uint64_t mine = lo[4 * r + 1 + (uint64_t)(lane & 3)];
+    const uint64_t a1 = readlane_u64(mine, 0), e1 = readlane_u64(mine, 1), a3 = readlane_u64(mine, 2), e3 = readlane_u64(mine, 3);
+    LineJob s, q;
+    line_begin(s, text, n, a1, e1, span_sum, lane);
+    line_begin(q, text, n, a3, e3, span_sum, lane);
+    line_finish<false>(s, text, n, 4 * r + 1, span_sum, lut, lane, lra);
+    line_finish<true>(q, text, n, 4 * r + 3, span_sum, lut, lane, lra);
 }
 
 template <bool WHOLE>

@@ -270,6 +270,12 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // ---- byte classification shared by the per-read kernels and the FASTQ text kernels ------------------------------
 struct Acc {
     uint32_t gcs, n, qb;

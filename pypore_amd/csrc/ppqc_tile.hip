@@ -119,12 +119,6 @@ struct TileCtx {
     bool line;      // line mode (FASTQ text): the sums of header and '+' lines (even line numbers) are never read
 };
 
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
-    return ((uint64_t)hi << 32) | lo;
-}
-
 // offsets[r + 1] (the end of read r < R) out of the register window; one coalesced load refills it every 64 reads, so
 // a boundary does not wait for a dependent global load
 __device__ __forceinline__ uint64_t read_end(Walk& w, const TileCtx& c, uint64_t r) {
