@@ -54,6 +54,7 @@ def parse(argv=None):
                     help="BASELINE config 5 instead of the headline metric: the same reads streamed from pinned host "
                          "memory as 4000-read batches through the double-buffered ppqc_submit (end to end incl. H2D)")
     ap.add_argument("--batch-reads", type=int, default=4000)
+    ap.add_argument("--fastq-reads", type=int, default=200_000, help="with --fastq: records of the text (the first of the workload's reads)")
     ap.add_argument("--fastq-resident-only", action="store_true", help="with --fastq: only the leg with the text resident in HBM (A/B runs)")
     ap.add_argument("--fastq", action="store_true",
                     help="FASTQ TEXT as input instead of CSR (not the headline metric): GPU tokenizer on text resident in "
@@ -572,7 +573,7 @@ def fastq_mode(a, ctx, torch, off, ch, t, d_bases, d_quals):
     """FASTQ text in, tables out.  The first `--reads` (capped at 200 000) synthetic reads are written as albacore-style
     4-line records, `batch_reads` per file."""
     from pypore_amd import qc, fastq_io
-    R = min(len(off) - 1, 200_000)
+    R = min(len(off) - 1, a.fastq_reads)
     nb = int(off[R])
     hb = d_bases[:nb].cpu().numpy().tobytes()
     hq = d_quals[:nb].cpu().numpy().tobytes()

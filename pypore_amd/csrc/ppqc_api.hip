@@ -646,7 +646,11 @@ int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
 
 // FASTQ text resident in device memory -> per-read arrays (see ppqc_fastq_gpu.hip).  One host synchronisation: the
 // number of lines has to be known to size the line table and the per-read arrays.
-constexpr int64_t kFastqSumsMinLine = 2048;   // mean bytes per line (headers and '+' lines included) from which the span sums pay
+// Mean bytes per line (headers and '+' lines included) from which the span sums pay: line_sum_kernel costs a wave per
+// record whatever its length.  tools/sweep_fastq_sums.sh, texts of 2 to 4 GB, second pass / span sums: mean read length
+// 500 b (270 B per line) 3.51 / 4.01 ms, 1 kb (520 B) 1.93 / 2.00, 2 kb (1020 B) 2.75 / 2.50, 4 kb 0.99 / 0.80 (0.8 GB),
+// 10 kb 1.65 / 1.27 (4 GB).
+constexpr int64_t kFastqSumsMinLine = 768;
 static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, uint64_t* n_records) {
     if (n_records) *n_records = 0;
     if (n == 0) return PPQC_OK;
@@ -666,16 +670,16 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     // instead of a second pass over the text (ppqc_fastq_gpu.hip).  It pays when the two end spans of a line are a small
     // part of it; the scan has to be chosen before the line count is known, so the last text's mean line length decides
     // (the first text of a context is taken to be long; a wrong guess costs the scan pass its extra arithmetic, nothing
-    // else).  PPQC_FASTQ_SUMS = 0 | 2: never / whenever the line ends fit the notes (A/B runs and tests).
+    // else).  PPQC_FASTQ_SUMS = 0 | 2: never / always (A/B runs and tests).
     const char* fs_env = getenv("PPQC_FASTQ_SUMS");
     const int fs_mode = fs_env ? atoi(fs_env) : 1;
     const bool with_sums = fs_mode == 2 || (fs_mode == 1 && (c->fq_line_hint < 0 || c->fq_line_hint >= kFastqSumsMinLine));
     HIPCHK(launch_nl_scan(text, n, c->fq, h + 1, c->ev_fq, s, with_sums ? c->lut_dev : nullptr));   // the scan's top kernel writes them
     HIPCHK(hipEventSynchronize(c->ev_fq));
     const uint64_t n_lines = h[1] + (((uint8_t)h[3]) != '\n' ? 1 : 0);
-    const bool sparse = h[2] == 0;
+    const uint64_t n_over = h[2];   // chunks with more line ends than their notes hold
     c->fq_line_hint = n_lines ? (int64_t)(n / n_lines) : -1;
-    const bool from_sums = with_sums && sparse && (fs_mode == 2 || c->fq_line_hint >= kFastqSumsMinLine);
+    const bool from_sums = with_sums && (fs_mode == 2 || c->fq_line_hint >= kFastqSumsMinLine);
     if (n_lines % 4 != 0)
         return fail(PPQC_E_INVALID, "FASTQ text has " + std::to_string(n_lines) + " lines, not a multiple of 4 (blank "
                                         "lines or multi-line records: use ppqc_fastq_scan / ppqc_fastq_pack)");
@@ -687,7 +691,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
         CHK(grow(&c->lra.rec_cnt, 0, cap, s)); CHK(grow(&c->lra.rec_hi, 0, cap, s)); CHK(grow(&c->lra.rec_lo, 0, cap, s));
         c->cap_lines = cap;
     }
-    HIPCHK(launch_nl_place(text, n, n_lines, sparse, c->fq, c->res_buf + c->res_words, s));
+    HIPCHK(launch_nl_place(text, n, n_lines, n_over, c->fq, c->res_buf + c->res_words, s));
     CHK(ensure_reads(c, c->n_reads + R));
     const uint32_t shift = kDefaultTileShift;
     CHK(ensure_tiles(c, (n + (1ull << shift) - 1) >> shift));

@@ -60,10 +60,14 @@ __device__ __forceinline__ uint32_t vec_badq_bits(const uint4& v, int valid) {
     return bits;
 }
 
-// nonzero iff some byte of the word lies outside '!'..'~' (newlines, other white space and invalid quality bytes)
-__device__ __forceinline__ uint32_t odd_byte_mask(uint32_t x) {
-    const uint32_t H = 0x80808080u, lo7 = x & 0x7F7F7F7Fu;
-    return ((x | (lo7 + 0x01010101u)) & H) | (~(lo7 + 0x5F5F5F5Fu) & H);
+// true iff some byte of the 16-byte vector lies outside '!'..'~' (newlines, other white space and invalid quality bytes);
+// the four words are folded before the test
+__device__ __forceinline__ bool vec_is_odd(const uint4& v) {
+    const uint32_t M = 0x7F7F7F7Fu, one = 0x01010101u, lowest = 0x5F5F5F5Fu;
+    const uint32_t a0 = v.x & M, a1 = v.y & M, a2 = v.z & M, a3 = v.w & M;
+    const uint32_t high = (v.x | v.y | v.z | v.w) | (a0 + one) | (a1 + one) | (a2 + one) | (a3 + one);   // a byte >= 0x7F
+    const uint32_t ge = (a0 + lowest) & (a1 + lowest) & (a2 + lowest) & (a3 + lowest);                    // every byte >= '!'
+    return ((high | ~ge) & 0x80808080u) != 0;
 }
 
 __device__ __forceinline__ uint4 load_vec_clamped(const uint8_t* __restrict__ text, uint64_t pos, uint64_t n) {
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void nl_scan_kernel(const uint8_t* __restrict_
         const uint4& v = vv[it];
         uint32_t bits = 0, bad = 0;
         // nearly every vector holds only '!'..'~' bytes: one cheap test, the exact masks only where it fires
-        const bool oddv = pos < n && (odd_byte_mask(v.x) | odd_byte_mask(v.y) | odd_byte_mask(v.z) | odd_byte_mask(v.w));
+        const bool oddv = pos < n && vec_is_odd(v);
         if (oddv) {
             const uint64_t rem = n - pos;
             bits = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
@@ -273,6 +277,7 @@ __global__ __launch_bounds__(256) void nl_place_kernel(const uint64_t* __restric
     for (int q = 0; q < kPlaceIlp; ++q) {
         const bool live = chunk0 + q < n_chunks;
         ne[q] = live ? n_entries[chunk0 + q] : 0;
+        if (ne[q] > (uint32_t)kNlEntries) ne[q] = 0;   // an overflowed list is incomplete: nl_fill_kernel takes the chunk
         pf[q] = live ? prefix[chunk0 + q] : 0;
     }
 #pragma unroll
@@ -309,11 +314,13 @@ __global__ __launch_bounds__(256) void nl_place_kernel(const uint64_t* __restric
 __global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict__ text, uint64_t n,
                                                       const uint64_t* __restrict__ prefix, uint64_t n_chunks,
                                                       uint64_t* __restrict__ line_off, uint64_t n_lines,
-                                                      uint64_t* __restrict__ errors) {
+                                                      uint64_t* __restrict__ errors, const uint32_t* __restrict__ only_over) {
     const int lane = threadIdx.x & 63;
     const uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0) { line_off[0] = 0; line_off[n_lines] = n; }
     if (chunk >= n_chunks) return;
+    // only_over: behind nl_place_kernel, for the chunks whose list of odd vectors overflowed (the others are placed)
+    if (only_over && only_over[chunk] <= (uint32_t)kNlEntries) return;
     uint64_t base = uniform_u64(prefix[chunk]);
     uint32_t nbad = 0;
     constexpr int kIt = (int)(kNlChunk / kSpan);
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict_
         uint32_t bits = 0, bad = 0;
         // nearly every vector holds only '!'..'~' bytes: one cheap test, the exact masks only where it fires
         const uint4& v = vv[it];
-        if (pos < n && (odd_byte_mask(v.x) | odd_byte_mask(v.y) | odd_byte_mask(v.z) | odd_byte_mask(v.w))) {
+        if (pos < n && vec_is_odd(v)) {
             const uint64_t rem = n - pos;
             bits = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
             bad = vec_badq_bits(v, rem < 16 ? (int)rem : 16);
@@ -395,17 +402,22 @@ hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& f
 
 // line_off[0] = 0, line_off[k + 1] = position after the k-th newline, line_off[n_lines] = n; errors[3] += bytes of quality
 // lines outside '!'..'~' (white space excepted).  `sparse`: from the entries of pass 1; else by a second pass over the text.
-hipError_t launch_nl_place(const uint8_t* text, uint64_t n, uint64_t n_lines, bool sparse, const FastqScratch& fs,
+// n_over: chunks whose list of odd vectors overflowed.  None: everything from the notes.  A few (a run of short reads
+// somewhere in a text of long ones): those chunks are read again, the rest comes from the notes.  Many: one pass over
+// the whole text, no notes.
+hipError_t launch_nl_place(const uint8_t* text, uint64_t n, uint64_t n_lines, uint64_t n_over, const FastqScratch& fs,
                            uint64_t* errors, hipStream_t s) {
     const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
-    if (sparse) {
+    const bool all = n_over * 8 >= n_chunks && n_over != 0;
+    if (!all) {
         const uint64_t blocks = n_chunks ? (n_chunks + 8 * kPlaceIlp - 1) / (8 * kPlaceIlp) : 1;
         hipLaunchKernelGGL(nl_place_kernel, dim3((unsigned)blocks), dim3(256), 0, s, fs.prefix, fs.n_entries, fs.entries,
                            n_chunks, fs.line_off, n, n_lines, errors);
-    } else {
+    }
+    if (n_over) {
         const uint64_t blocks = n_chunks ? (n_chunks + 3) / 4 : 1;
         hipLaunchKernelGGL(nl_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, text, n, fs.prefix, n_chunks, fs.line_off,
-                           n_lines, errors);
+                           n_lines, errors, all ? (const uint32_t*)nullptr : fs.n_entries);
     }
     return hipGetLastError();
 }

@@ -169,7 +169,7 @@ hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& f
 // whole lines from the span sums (sequence and quality line of every record) into line_ra.rec_*
 hipError_t launch_line_sums(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
                             const uint64_t* span_sum, const uint64_t* lut_dev, ReadArrays line_ra, hipStream_t s);
-hipError_t launch_nl_place(const uint8_t* text, uint64_t n, uint64_t n_lines, bool sparse, const FastqScratch& fs,
+hipError_t launch_nl_place(const uint8_t* text, uint64_t n, uint64_t n_lines, uint64_t n_over, const FastqScratch& fs,
                            uint64_t* errors, hipStream_t s);
 // one thread per record: validates the four lines, strips line ends, merges the line sums into the per-read arrays,
 // parses ch= and start_time= out of the header.  errors[1] counts malformed records.

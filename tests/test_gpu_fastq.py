@@ -268,3 +268,20 @@ def test_header_fuzz_against_the_host_packer(qc_mod, c_oracle):
         tables = ctx.finalize()
     _check(got, want)
     assert_tables_equal(tables, wt)
+
+
+def test_a_run_of_short_reads_inside_long_ones(qc_mod, c_oracle):
+    """A few chunks of the text hold more line ends than their notes (32 vectors per 8 KiB): only those chunks are read
+    again for their line starts, the rest of the text is placed from the notes -- and with many such chunks the whole
+    text takes the second pass.  Same records and tables as the host packer in every mix."""
+    for seed, lens in ((31, [9000] * 30 + [3] * 400 + [12000] * 30 + [0] * 200 + [70000, 5]),
+                       (32, [2] * 900 + [20000] * 3),
+                       (33, [15000] * 20 + [1] * 40 + [15000] * 20)):
+        text = _text(seed, len(lens), lens=lens, crlf=bool(seed % 2))
+        p, want, wt = _host_path(qc_mod, c_oracle, text)
+        with qc_mod.QCContext(device=0, **CFG) as ctx:
+            assert ctx.submit_fastq(text) == len(lens)
+            got = ctx.read_stats()
+            tables = ctx.finalize()
+        _check(got, want)
+        assert_tables_equal(tables, wt, str(seed))
