@@ -607,7 +607,8 @@ def fastq_mode(a, ctx, torch, off, ch, t, d_bases, d_quals):
             tab = fn()
         ctx.sync()
         dt = (time.perf_counter() - t0) / a.steps
-        assert int(tab["totals"][0]) == R and int(tab["totals"][1]) == nb and int(tab["totals"][7]) == 0
+        if not os.environ.get("PPQC_BENCH_NOCHECK"):   # knock-out builds of the kernels (tools/ab_fastq.sh) give wrong sums
+            assert int(tab["totals"][0]) == R and int(tab["totals"][1]) == nb and int(tab["totals"][7]) == 0
         res[name] = {"ms": round(dt * 1e3, 3), "Gbases_per_s": round(nb / dt / 1e9, 2), "text_GBps": round(total / dt / 1e9, 2)}
         return {k: np.array(v) for k, v in tab.items()}   # the next path overwrites the pinned buffer the views show
 
