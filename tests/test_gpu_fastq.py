@@ -285,3 +285,57 @@ def test_a_run_of_short_reads_inside_long_ones(qc_mod, c_oracle):
             tables = ctx.finalize()
         _check(got, want)
         assert_tables_equal(tables, wt, str(seed))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzzed_texts_around_span_edges(qc_mod, c_oracle, seed):
+    """Random texts aimed at the span sums: lines that start or end on, just before or just behind a 1 KiB span edge,
+    lines inside one span, empty lines, lines of many spans; quality lines of nothing but bytes at or above '@' (the scan
+    pass then takes them for sequence and the line sums must come from the text), sequence lines with bytes below '@',
+    blanks inside lines (a span without sums inside a line), headers longer than a span, LF / CRLF, with and without the
+    last line end.  Both ways of making the line sums against the host packer and the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    crlf = bool(seed % 2)
+    nl = b"\r\n" if crlf else b"\n"
+    out, pos = [], 0
+    for i in range(int(rng.integers(150, 400))):
+        kind = int(rng.integers(0, 8))
+        if kind == 0:
+            L = int(rng.integers(0, 3))
+        elif kind == 1:
+            L = int(rng.integers(1, 900))
+        elif kind == 2:
+            L = 1024 * int(rng.integers(1, 6)) + int(rng.integers(-3, 4))
+        elif kind == 3:
+            L = int(rng.integers(3000, 40000))
+        elif kind == 4:
+            L = int(rng.integers(60000, 140000))
+        else:
+            L = int(rng.integers(900, 6000))
+        title = b"r%d ch=%d start_time=2018-06-03T%02d:00:00Z" % (i, int(rng.integers(1, 513)), int(rng.integers(0, 24)))
+        if kind == 5:
+            title += b" " + b"k" * int(rng.integers(1000, 2500))
+        if kind in (2, 6):      # put the start of the sequence line on (or next to) a span edge
+            pad = (-(pos + 1 + len(title) + len(nl))) % 1024 + int(rng.integers(-2, 3))
+            if pad > 2:
+                title += b" " + b"p" * (pad - 1)
+        seq = rng.choice(ALPH, L)
+        hiq = int(rng.integers(0, 3)) == 0
+        qual = rng.integers(64 if hiq else 33, 127, L, dtype=np.uint8)
+        if L > 50 and kind == 7:
+            seq = seq.copy()
+            seq[rng.integers(0, L, 3)] = np.frombuffer(b"*-.", np.uint8)       # bytes below '@' inside a sequence
+            qual[rng.integers(0, L - 1, 2)] = 32                                # blanks inside (not at the end of) a quality line
+        rec = b"@" + title + nl + bytes(seq) + nl + b"+" + nl + bytes(qual) + nl
+        out.append(rec); pos += len(rec)
+    text = b"".join(out)
+    if seed % 3 == 0:
+        text = text[:-len(nl)]
+    p, want, wt = _host_path(qc_mod, c_oracle, text)
+    assert p["n_reads"] == len(out)
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        assert ctx.submit_fastq(text) == len(out)
+        got = ctx.read_stats()
+        tables = ctx.finalize()
+    _check(got, want)
+    assert_tables_equal(tables, wt, str(seed))
