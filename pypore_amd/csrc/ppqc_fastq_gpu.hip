@@ -106,7 +106,9 @@ constexpr int kNlEntries = (int)kNlEntriesPerChunk;
 constexpr uint64_t kSpanHas = 1ull << 63, kSpanQual = 1ull << 62;
 
 // entry = vector index in the chunk (bits 32..41) | newline bits (0..15) | invalid-quality bits (16..31)
-template <bool SUMS>
+// NOTES = false (a text of short lines, whose notes would overflow in most chunks and be thrown away): newlines are
+// counted, nothing else.
+template <bool SUMS, bool NOTES = true>
 __global__ __launch_bounds__(256) void nl_scan_kernel(const uint8_t* __restrict__ text, uint64_t n,
                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ n_entries,
                                                       uint64_t* __restrict__ entries, uint64_t n_chunks,
@@ -139,11 +141,11 @@ __global__ __launch_bounds__(256) void nl_scan_kernel(const uint8_t* __restrict_
         if (oddv) {
             const uint64_t rem = n - pos;
             bits = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
-            bad = vec_badq_bits(v, rem < 16 ? (int)rem : 16);
+            if (NOTES) bad = vec_badq_bits(v, rem < 16 ? (int)rem : 16);
         }
         cnt += __popc(bits);
-        const uint64_t odd = __ballot((bits | bad) != 0);
-        if (odd) {
+        const uint64_t odd = NOTES ? __ballot((bits | bad) != 0) : 0ull;
+        if (NOTES && odd) {
             const uint32_t at = ne + __builtin_amdgcn_mbcnt_hi((uint32_t)(odd >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)odd, 0u));
             if ((bits | bad) != 0 && at < (uint32_t)kNlEntries)
                 entries[chunk * kNlEntries + at] = ((uint64_t)(it * 64 + lane) << 32) | ((uint64_t)bad << 16) | bits;
@@ -178,8 +180,8 @@ __global__ __launch_bounds__(256) void nl_scan_kernel(const uint8_t* __restrict_
     cnt = wave_sum_u32(cnt);
     if (lane == 0) {
         counts[chunk] = cnt;
-        n_entries[chunk] = ne;
-        if (ne > (uint32_t)kNlEntries) atomicAdd((unsigned long long*)overflow, 1ull);
+        n_entries[chunk] = NOTES ? ne : (uint32_t)kNlEntries + 1u;   // no notes: as if the list had overflowed
+        if (NOTES && ne > (uint32_t)kNlEntries) atomicAdd((unsigned long long*)overflow, 1ull);
     }
 }
 
@@ -376,16 +378,20 @@ __global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict_
 // Pass 1 and the scan: counts, entries and the chunks' line numbers; fs.prefix[n_chunks] = newlines of the text,
 // fs.prefix[n_chunks + 1] = chunks whose entry list overflowed.
 hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, uint64_t* host_out, hipEvent_t counted,
-                          hipStream_t s, const uint64_t* lut_dev) {
+                          hipStream_t s, const uint64_t* lut_dev, bool notes) {
     const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
     hipError_t e = hipMemsetAsync(fs.prefix + n_chunks, 0, 16, s);
     if (e != hipSuccess || n_chunks == 0) return e;
     if (lut_dev)   // with span sums (fs.span_sum holds two words per 1 KiB span of every chunk)
         hipLaunchKernelGGL(nl_scan_kernel<true>, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, text, n, fs.counts,
                            fs.n_entries, fs.entries, n_chunks, fs.prefix + n_chunks + 1, fs.span_sum, lut_dev);
-    else
+    else if (notes)
         hipLaunchKernelGGL(nl_scan_kernel<false>, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, text, n, fs.counts,
                            fs.n_entries, fs.entries, n_chunks, fs.prefix + n_chunks + 1, (uint64_t*)nullptr,
+                           (const uint64_t*)nullptr);
+    else
+        hipLaunchKernelGGL((nl_scan_kernel<false, false>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, text, n,
+                           fs.counts, fs.n_entries, fs.entries, n_chunks, fs.prefix + n_chunks + 1, (uint64_t*)nullptr,
                            (const uint64_t*)nullptr);
     const uint64_t nblocks = (n_chunks + kScanBlock - 1) / kScanBlock;
     hipLaunchKernelGGL(nl_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, fs.counts, n_chunks, fs.block_sums);
@@ -689,17 +695,36 @@ __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __re
     const uint64_t g = read_base + r;
     uint64_t a[4], e[4];
     uint64_t strip_qb = 0, strip_err = 0;   // what the stripped end of the quality line added to its raw sums
+    // The last kTailBytes bytes of all four lines and the first of lines 1 and 3 are requested before any is looked at
+    // (a line end is one or two bytes; walking back byte by byte, line by line, was a chain of eight dependent loads).
+    constexpr int kTailBytes = 3;
+    uint8_t tb[4][kTailBytes];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         a[k] = lo[4 * r + k];
         e[k] = lo[4 * r + k + 1];
-        while (e[k] > a[k] && is_space(text[e[k] - 1])) {   // '\n', "\r\n", trailing blanks: what rstrip() removes
-            --e[k];
-            if (k == 3) { strip_qb += text[e[k]]; strip_err += lut[text[e[k]]]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < kTailBytes; ++j) tb[k][j] = e[k] >= a[k] + (uint64_t)j + 1 ? text[e[k] - 1 - j] : (uint8_t)'x';
+    const uint8_t first0 = e[0] > a[0] ? text[a[0]] : (uint8_t)0, first2 = e[2] > a[2] ? text[a[2]] : (uint8_t)0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int j = 0;
+        while (j < kTailBytes && is_space(tb[k][j])) {   // '\n', "\r\n", trailing blanks: what rstrip() removes
+            if (k == 3) { strip_qb += tb[k][j]; strip_err += lut[tb[k][j]]; }
+            ++j;
         }
+        e[k] -= (uint64_t)j;
+        if (j == kTailBytes)
+            while (e[k] > a[k] && is_space(text[e[k] - 1])) {
+                --e[k];
+                if (k == 3) { strip_qb += text[e[k]]; strip_err += lut[text[e[k]]]; }
+            }
     }
     const uint64_t L = e[1] - a[1];
-    bool ok = e[0] > a[0] && text[a[0]] == '@' && e[2] > a[2] && text[a[2]] == '+' && L == e[3] - a[3] && L < 0xFFFFFFFFull;
+    bool ok = e[0] > a[0] && first0 == '@' && e[2] > a[2] && first2 == '+' && L == e[3] - a[3] && L < 0xFFFFFFFFull;
     if (ok && e[2] - a[2] > 1) {   // an optional repeated title must match (SeqIO: "captions differ")
         ok = e[2] - a[2] == e[0] - a[0];
         for (uint64_t i = 1; ok && i < e[2] - a[2]; ++i) ok = text[a[2] + i] == text[a[0] + i];

@@ -165,7 +165,7 @@ struct FastqScratch {
 uint64_t nl_scan_block_words(uint64_t n_chunks);
 // lut_dev != nullptr: the pass also leaves the span sums in fs.span_sum
 hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, uint64_t* host_out, hipEvent_t counted,
-                          hipStream_t s, const uint64_t* lut_dev = nullptr);
+                          hipStream_t s, const uint64_t* lut_dev = nullptr, bool notes = true);   // notes = false: count only
 // whole lines from the span sums (sequence and quality line of every record) into line_ra.rec_*
 hipError_t launch_line_sums(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
                             const uint64_t* span_sum, const uint64_t* lut_dev, ReadArrays line_ra, hipStream_t s);

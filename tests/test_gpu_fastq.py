@@ -13,11 +13,12 @@ CFG = dict(n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=
 ALPH = np.frombuffer(b"ACGTACGTNnacgtSs", np.uint8)
 
 
-@pytest.fixture(autouse=True, params=["0", "2"], ids=["second_pass", "span_sums"])
+@pytest.fixture(autouse=True, params=["0", "2", "1"], ids=["second_pass", "span_sums", "auto"])
 def line_sums_from(request, monkeypatch):
     """Every test runs both ways the line sums are made: the line-mode tile kernel's second pass over the text
-    (PPQC_FASTQ_SUMS=0) and the span sums of the scan pass put together per line (2: whenever the notes hold every line
-    end; by default the library takes them for long lines only).  The library reads the variable at every submit."""
+    (PPQC_FASTQ_SUMS=0), the span sums of the scan pass put together per line (2), and the library's own choice (1, the
+    default: by the mean line length of the context's previous text -- span sums for long lines, a scan that only counts
+    for very short ones).  The library reads the variable at every submit."""
     monkeypatch.setenv("PPQC_FASTQ_SUMS", request.param)
     return request.param
 
@@ -185,6 +186,11 @@ def test_dense_text_takes_the_second_text_pass(qc_mod, c_oracle):
         assert ctx.submit_fastq(text) == len(recs)
         _check(ctx.read_stats(), want)
         assert ctx.input_errors()["bad_quality_bytes"] == p["n_bad_qual"] > 100
+        ctx.reset()
+        # the same text again: by its own choice the library now knows the lines are short and only counts in the scan
+        assert ctx.submit_fastq(text) == len(recs)
+        _check(ctx.read_stats(), want)
+        assert ctx.input_errors()["bad_quality_bytes"] == p["n_bad_qual"]
         ctx.reset()
         sparse = _text(13, 500)
         p2, want2, wt2 = _host_path(qc_mod, c_oracle, sparse)
