@@ -704,7 +704,8 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     // the whole 0.72 ms and fastq_finalize waits 50 us for the last of them.
     // ... line_sum_kernel is short and leaves room: beside it the header kernel is hidden (1.29 -> 1.265 ms for the step;
     // PPQC_FASTQ_HDR_AUX = 0 puts it back in front)
-    const bool hdr_aux = from_sums && !(getenv("PPQC_FASTQ_HDR_AUX") && atoi(getenv("PPQC_FASTQ_HDR_AUX")) == 0);
+    const int hdr_env = getenv("PPQC_FASTQ_HDR_AUX") ? atoi(getenv("PPQC_FASTQ_HDR_AUX")) : 1;
+    const bool hdr_aux = hdr_env == 2 || (from_sums && hdr_env != 0);
     if (hdr_aux) {
         HIPCHK(hipEventRecord(c->ev_fq, s));
         HIPCHK(hipStreamWaitEvent(c->aux, c->ev_fq, 0));
@@ -715,12 +716,12 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     }
     if (from_sums) {
         HIPCHK(launch_line_sums(text, n, R, c->fq.line_off, c->fq.span_sum, c->lut_dev, c->lra, s));
-        if (hdr_aux) HIPCHK(hipStreamWaitEvent(s, c->ev_hdr, 0));
     } else {
         // line mode: both classifiers run over the same text, every line is a segment
         BatchView v{text, text, c->fq.line_off, n_lines, n, nullptr, shift, nullptr, nullptr, nullptr};
         HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->dense, c->n_cu, s, true));
     }
+    if (hdr_aux) HIPCHK(hipStreamWaitEvent(s, c->ev_hdr, 0));
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
                                  c->lut_dev, c->tp.thr_fail, c->tp.fail_q, mux, c->res_buf + c->res_words, s, from_sums));
     c->n_reads += R;
