@@ -345,3 +345,38 @@ def test_fuzzed_texts_around_span_edges(qc_mod, c_oracle, seed):
         tables = ctx.finalize()
     _check(got, want)
     assert_tables_equal(tables, wt, str(seed))
+
+
+_BIG = {}
+
+
+def _big_text():
+    """0.4 GB of text, made once for the three ways the test below runs."""
+    if not _BIG:
+        rng = np.random.default_rng(99)
+        lens = np.clip(np.rint(rng.lognormal(8.5172, 1.1774, 20_000)), 1, 2_000_000).astype(np.int64)
+        nb = int(lens.sum())
+        hb = rng.choice(np.frombuffer(b"ACGTACGTACGTN", np.uint8), nb).tobytes()
+        hq = rng.integers(34, 70, nb, dtype=np.uint8).tobytes()
+        off = np.concatenate([[0], np.cumsum(lens)])
+        _BIG["text"] = b"".join(b"@r%d runid=f read=%d ch=%d start_time=2018-06-03T%02d:%02d:00Z\n%s\n+\n%s\n" % (
+            i, i, 1 + i % 512, i % 24, i % 60, hb[off[i]:off[i + 1]], hq[off[i]:off[i + 1]]) for i in range(len(lens)))
+        _BIG["n"], _BIG["nb"] = len(lens), nb
+    return _BIG["text"], _BIG["n"], _BIG["nb"]
+
+
+def test_a_text_of_long_reads_at_size(qc_mod, c_oracle):
+    """0.4 GB of text, 20 000 reads with the length distribution of BASELINE config 2 (lognormal, mean 10 kb, up to
+    hundreds of kb): every record and table against the host packer + C oracle, however the line sums are made."""
+    text, n_reads, nb = _big_text()
+    if "host" not in _BIG:
+        _BIG["host"] = _host_path(qc_mod, c_oracle, text)
+    p, want, wt = _BIG["host"]
+    assert p["n_reads"] == n_reads and int(want["length"].sum()) == nb
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        assert ctx.submit_fastq(text) == n_reads
+        got = ctx.read_stats()
+        tables = ctx.finalize()
+    _check(got, want)
+    assert_tables_equal(tables, wt)
+    assert int(tables["totals"][1]) == nb
