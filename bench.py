@@ -44,6 +44,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the short end-to-end (pinned host -> GPU) leg")
     ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the config-3 sharded leg")
+    ap.add_argument("--config3-reads", type=int, default=0, help="reads of the config-3 job (0: the 10 M of BASELINE config 3)")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="NOT a measurement: the N ranks share GPU 0 and talk over gloo, so that the whole N > 1 code path "
+                         "of this script (launch, sharding, merges, both workloads, reporting) can be run on a one-GPU box")
     ap.add_argument("--config3-leg", action="store_true",
                     help="with --dist-path on one GPU: run the config-3 sharded leg too (the whole 10 M-read job on one "
                          "rank, about 100 GB of HBM), to rehearse the N > 1 code path")
@@ -204,18 +208,24 @@ def main():
     import torch.distributed as dist
 
     n_dev = torch.cuda.device_count()
-    if n_dev < world or local >= n_dev:
+    if a.rehearse_gloo:
+        local = 0                      # every rank on GPU 0
+    if n_dev < 1 or (not a.rehearse_gloo and (n_dev < world or local >= n_dev)):
         sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s): refusing to run\n" % (a.gpus, n_dev))
         return 3
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or a.dist_path
     rccl_ranks = 1
+    cdev = torch.device("cpu") if a.rehearse_gloo else dev    # where this script's own small collectives live
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        one = torch.ones(1, dtype=torch.int64, device=dev)
+        if a.rehearse_gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        one = torch.ones(1, dtype=torch.int64, device=cdev)
         dist.all_reduce(one, op=dist.ReduceOp.SUM)      # the ranks RCCL really connects, not the ones asked for
         rccl_ranks = int(one.item())
         if rccl_ranks != world or dist.get_world_size() != world:
@@ -273,7 +283,7 @@ def main():
     def reduce_max(x):
         if world == 1:
             return x
-        tmax = torch.tensor([x], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([x], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item())
 
@@ -282,7 +292,7 @@ def main():
     ctx.reset_timings()
     dt, blocks, tables = timed_blocks(step, fence, a.steps, a.min_seconds, reduce_max)
     if world > 1:
-        tot = torch.tensor([n_bytes], dtype=torch.int64, device=dev)
+        tot = torch.tensor([n_bytes], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_bases = int(tot.item())
     else:
@@ -303,8 +313,10 @@ def main():
         alg_bytes = tm["tile_kernel_bytes"] / launches      # 2*B + 50*R per launch (BASELINE.md accounting)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
-            "metric": "Gbases/s per-read QC stats", "value": round(value, 2), "unit": "Gbases/s", "n_gpus": world,
-            "rccl_ranks": rccl_ranks if use_dist else 0,
+            "metric": "Gbases/s per-read QC stats" if not a.rehearse_gloo else
+                      "REHEARSAL, not a measurement: %d ranks sharing ONE GPU over gloo" % world,
+            "value": round(value, 2), "unit": "Gbases/s", "n_gpus": world,
+            "rccl_ranks": rccl_ranks if use_dist else 0, "backend": "gloo (rehearsal)" if a.rehearse_gloo else "nccl",
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "timed_blocks": blocks, "timed_seconds": round(dt * blocks, 3),
@@ -346,7 +358,7 @@ def config3_sharded(a, torch, dist, qc, synth, finalize_distributed, dev, local,
     the three N50-select rounds beside it).  Strong scaling: the job is the same for every N, and so are its tables
     (n50, totals): compare them across the SCALE runs."""
     c3 = synth.CONFIGS["config3"]
-    Rj = c3["n_reads"]
+    Rj = a.config3_reads or c3["n_reads"]
     lens = synth.read_lengths(Rj, c3["mu"], c3["sigma"], a.seed)
     off = synth.offsets_from_lengths(lens)
     ch, mux, t = synth.metadata(Rj, c3["n_channels"], c3["hours"], a.seed)
@@ -381,7 +393,7 @@ def config3_sharded(a, torch, dist, qc, synth, finalize_distributed, dev, local,
         torch.cuda.synchronize()
 
     def reduce_max(x):
-        tmax = torch.tensor([x], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([x], dtype=torch.float64, device=torch.device("cpu") if a.rehearse_gloo else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item())
 

@@ -61,3 +61,30 @@ def test_more_ranks_than_gpus_fails_loudly_on_the_gpu_box():
     """The same on the 1-GPU box: `python bench.py --gpus 2` without torchrun must fail, not report n_gpus 1.  The two
     ranks only count devices (which does not initialise the GPU) and leave."""
     test_more_ranks_than_gpus_fails_loudly_cpu()
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_rehearsal_on_one_gpu():
+    """The whole N = 2 path of bench.py on the one-GPU box: `python bench.py --gpus 2 --rehearse-gloo` starts its two
+    ranks itself, both on GPU 0, talking over gloo -- launch, per-rank workloads, finalize_distributed in every step, the
+    config-3 job cut contiguously over the ranks and merged (its totals and N50 must be the whole job's), MAX / SUM over
+    ranks, one JSON line from rank 0.  Not a measurement, and the line says so."""
+    rc, out, err = _run(["--gpus", "2", "--rehearse-gloo", "--steps", "2", "--warmup", "1", "--min-seconds", "0",
+                         "--reads", "60000", "--config3-reads", "150000", "--no-cpu-baseline", "--no-h2d"])
+    assert rc == 0, err[-3000:]
+    lines = _json_lines(out)
+    assert len(lines) == 1, out
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["backend"].startswith("gloo") and "REHEARSAL" in j["metric"]
+    assert j["config"]["reads_per_gpu"] == 60000 and j["value"] > 0
+    c3 = j["config3_sharded"]
+    assert "error" not in c3, c3
+    # the same job on one rank (the 1-rank RCCL group of --dist-path): same tables whatever the sharding
+    rc, out, err = _run(["--gpus", "1", "--dist-path", "--config3-leg", "--steps", "2", "--warmup", "1", "--min-seconds", "0",
+                         "--reads", "60000", "--config3-reads", "150000", "--no-cpu-baseline", "--no-h2d"])
+    assert rc == 0, err[-3000:]
+    one = _json_lines(out)[0]["config3_sharded"]
+    assert "error" not in one, one
+    for k in ("n50", "reads", "bases", "n_fail"):
+        assert c3[k] == one[k], (k, c3[k], one[k])
+    assert c3["reads"] == 150000 and c3["n_gpus"] == 2 and one["n_gpus"] == 1
