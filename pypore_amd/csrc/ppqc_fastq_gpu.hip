@@ -623,8 +623,18 @@ __device__ __forceinline__ void line_finish(LineJob& j, const uint8_t* __restric
                                             const ReadArrays& lra) {
     uint64_t c0 = 0, c1 = 0, hi = 0, lw = 0;
     if (j.e > j.a) {
-        edge_sum<QUAL>(j.v0, j.k0, j.a, j.e, lut, lane, c0, c1, hi, lw);
-        if (j.k1 != j.k0) edge_sum<QUAL>(j.v1, j.k1, j.a, j.e, lut, lane, c0, c1, hi, lw);
+        // The first span of the line uses the lanes from la on, the last one the lanes up to lb: when these do not meet
+        // (every other line), ONE pass takes both, each lane with the vector of its span.
+        const int la = (int)((j.a - j.k0 * kSpan) / kVec), lb = (int)((j.e - 1 - j.k1 * kSpan) / kVec);
+        if (j.k1 != j.k0 && lb < la) {
+            const bool first = lane >= la;
+            const uint4 v = make_uint4(first ? j.v0.x : j.v1.x, first ? j.v0.y : j.v1.y, first ? j.v0.z : j.v1.z,
+                                       first ? j.v0.w : j.v1.w);
+            edge_sum<QUAL>(v, first ? j.k0 : j.k1, j.a, j.e, lut, lane, c0, c1, hi, lw);
+        } else {
+            edge_sum<QUAL>(j.v0, j.k0, j.a, j.e, lut, lane, c0, c1, hi, lw);
+            if (j.k1 != j.k0) edge_sum<QUAL>(j.v1, j.k1, j.a, j.e, lut, lane, c0, c1, hi, lw);
+        }
         for (uint64_t kb = j.k0 + 1; kb < j.k1; kb += 64) {   // wave-uniform; the first round's span sums are loaded
             if (kb != j.k0 + 1) {
                 const uint64_t k = kb + (uint64_t)lane;
