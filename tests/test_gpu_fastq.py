@@ -293,7 +293,7 @@ def test_a_run_of_short_reads_inside_long_ones(qc_mod, c_oracle):
         assert_tables_equal(tables, wt, str(seed))
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PPQC_FUZZ_SEEDS", "10"))))   # more for a longer run
 def test_fuzzed_texts_around_span_edges(qc_mod, c_oracle, seed):
     """Random texts aimed at the span sums: lines that start or end on, just before or just behind a 1 KiB span edge,
     lines inside one span, empty lines, lines of many spans; quality lines of nothing but bytes at or above '@' (the scan
