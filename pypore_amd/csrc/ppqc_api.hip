@@ -699,11 +699,11 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     CHK(ensure_reads(c, c->n_reads + R));
     const uint32_t shift = kDefaultTileShift;
     CHK(ensure_tiles(c, (n + (1ull << shift) - 1) >> shift));
-    // The headers need the line table only.  Their kernel runs in front of the tile kernel on the same stream: beside it
-    // on the auxiliary stream (also at the highest stream priority) its blocks trickle in between the tile kernel's for
-    // the whole 0.72 ms and fastq_finalize waits 50 us for the last of them.
-    // ... line_sum_kernel is short and leaves room: beside it the header kernel is hidden (1.29 -> 1.265 ms for the step;
-    // PPQC_FASTQ_HDR_AUX = 0 puts it back in front)
+    // The headers need the line table only.  In front of the line-mode tile kernel their kernel runs on the same stream:
+    // beside it on the auxiliary stream (also at the highest stream priority) its blocks trickle in between the tile
+    // kernel's for the whole 0.72 ms and fastq_finalize waits 50 us for the last of them.  line_sum_kernel is short and
+    // leaves room: beside it the header kernel is hidden (1.29 -> 1.265 ms for the step).  PPQC_FASTQ_HDR_AUX = 0 | 2:
+    // always in front / always beside.
     const int hdr_env = getenv("PPQC_FASTQ_HDR_AUX") ? atoi(getenv("PPQC_FASTQ_HDR_AUX")) : 1;
     const bool hdr_aux = hdr_env == 2 || (from_sums && hdr_env != 0);
     if (hdr_aux) {

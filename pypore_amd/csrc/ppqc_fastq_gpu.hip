@@ -6,14 +6,18 @@
 // ppqc_fastq_scan/pack accepts blank lines between records and reports the record number).
 //
 // The text is never compacted into separate base / quality streams.  Instead:
-//   1. the table of line starts: one streaming pass over the text that counts newlines and notes the few vectors that hold
-//      one, a scan, and a placement from those notes (a second pass over the text only when lines are short);
-//   2. the per-read tile kernel runs in "line mode": bases = quals = text, offsets = line starts, so every LINE gets
-//      the raw sums of both classifiers (G/C/S and N counts, quality byte sum, fixed-point error sum);
-//   3. fastq_finalize (one thread per record) takes the base sums of line 2 and the quality sums of line 4, removes
-//      the contribution of the stripped line end from the quality sums, validates the record and writes the same
-//      per-read arrays finalize_reads writes.
-// Traffic: two reads of the text (2.05 bytes per base each; three when lines are short) and no write of the sequence bytes.
+//   1. ONE streaming pass over the text (nl_scan_kernel) counts newlines, notes the few vectors that hold a line end and,
+//      for texts of long lines, sums every 1 KiB span that lies inside one line with the classifier its bytes suggest
+//      (span sums); a scan numbers the lines, and nl_place_kernel places the line starts from the notes (chunks whose
+//      notes overflowed are read again, a text of short lines as a whole: nl_fill_kernel);
+//   2. the raw sums of every sequence and quality line: for long lines from the span sums, with only the two end spans
+//      of a line read from the text (line_sum_kernel); for short lines by the per-read tile kernel in "line mode"
+//      (bases = quals = text, offsets = line starts: a second pass over the text);
+//   3. fastq_header_kernel parses ch= and start_time= out of the headers; fastq_finalize_kernel (one thread per record)
+//      takes the base sums of line 2 and the quality sums of line 4, removes the contribution of the stripped line end
+//      from the quality sums, validates the record and writes the same per-read arrays finalize_reads writes.
+// Traffic: 1.19 reads of the text for long reads (profiles/r02*_bench_fastq_pmc_hbm.json), two to three for short ones,
+// and no write of the sequence bytes.
 #include "ppqc_internal.hpp"
 
 namespace ppqc {
