@@ -31,12 +31,34 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def _compile_one(args):
+    hipcc, src, obj, verbose = args
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return obj
+
+
 def build(force=False, verbose=False):
+    """One object per translation unit (compiled side by side, only those older than their sources), then one link."""
     if not force and not needs_build():
         return OUT
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           "-o", OUT] + [os.path.join(HERE, "csrc", s) for s in SRC]
+    objdir = os.path.join(HERE, "csrc", "build")
+    os.makedirs(objdir, exist_ok=True)
+    common = [os.path.join(HERE, "csrc", "ppqc_internal.hpp"), os.path.join(HERE, "..", "include", "pypore_qc.h")]
+    t_common = max(os.path.getmtime(d) for d in common)
+    jobs, objs = [], []
+    for s in SRC:
+        src, obj = os.path.join(HERE, "csrc", s), os.path.join(objdir, s + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), t_common):
+            jobs.append((hipcc, src, obj, verbose))
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(_compile_one, jobs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", OUT] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

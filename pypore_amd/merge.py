@@ -34,11 +34,16 @@ def allreduce_table_tensors(sum_t, max_t, min_t, dist, group=None):
     dist.all_reduce(sum_t, op=dist.ReduceOp.SUM, group=group)
 
 
+def _gloo(dist, group):
+    return dist.get_backend(group) == "gloo"
+
+
 def gather_lengths(lengths_t, dist, torch, group=None):
     """All-gather of per-rank length vectors of different sizes (zero padding does not change N50)."""
     world = dist.get_world_size(group)
-    if lengths_t.is_cuda and dist.get_backend(group) == "gloo":
-        torch.cuda.current_stream().synchronize()      # see _all_reduce
+    dev = lengths_t.device
+    if lengths_t.is_cuda and _gloo(dist, group):
+        lengths_t = lengths_t.cpu()                    # gloo only ever sees host memory: see _all_reduce
     n = torch.tensor([lengths_t.numel()], dtype=torch.int64, device=lengths_t.device)
     dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
     nmax = int(n.item())
@@ -46,16 +51,29 @@ def gather_lengths(lengths_t, dist, torch, group=None):
     padded[: lengths_t.numel()] = lengths_t
     out = torch.empty(nmax * world, dtype=lengths_t.dtype, device=lengths_t.device)
     dist.all_gather_into_tensor(out, padded, group=group)
-    return out
+    return out.to(dev)
 
 
 def _all_reduce(dist, torch, t, op, group=None):
-    """dist.all_reduce of a device tensor.  RCCL ("nccl") is stream-ordered: nothing waits.  gloo (the two-ranks-on-one-GPU
-    rehearsal and the CPU tests) stages a device tensor through the host from a worker thread; handed a tensor whose
-    producer kernels are still queued on the stream it hung about one run in three on this pool, and never when the
-    stream was idle: the stream is drained first, which costs that backend nothing it was not going to pay."""
-    if t.is_cuda and dist.get_backend(group) == "gloo":
-        torch.cuda.current_stream().synchronize()
+    """dist.all_reduce of a device tensor, in place.
+
+    RCCL ("nccl") enqueues the collective on the issuing stream's order and nothing waits on the host.
+
+    gloo (the CPU tests and the rehearsals with several ranks on one GPU) has no device path of its own: handed a device
+    tensor, ProcessGroupGloo copies it to pinned memory on a high-priority pool stream that waits for the issuing stream,
+    and a worker thread blocks in that pool stream's synchronize() before the host exchange.  With two processes sharing
+    one GPU that wait did not return when kernels were still queued in front of it (five recorded runs, both ranks inside
+    work.wait() of one and the same collective, at two collectives whose producers share nothing -- one of them a kernel
+    on the very stream the collective was issued on, so no event can have been missing; a missing event gives wrong
+    values, not a wait without end, and the library enqueues no kernel that waits for anything: DESIGN section 5).  So
+    gloo is never handed device memory here: the tensor is copied to the host in stream order (which waits for exactly
+    its producers), reduced there, and copied back.  Every gloo collective of this package goes through this function,
+    ``gather_lengths`` or ``allreduce_min_int``, which do the same."""
+    if t.is_cuda and _gloo(dist, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+        return
     dist.all_reduce(t, op=op, group=group)
 
 
@@ -63,11 +81,12 @@ _SIDE = {}
 
 
 def _side_stream(torch):
-    """One extra stream per device for the merges that run beside the per-read kernel."""
-    dev = torch.cuda.current_device()
-    if dev not in _SIDE:
-        _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return _SIDE[dev]
+    """One extra stream per device and driving thread for the merges that run beside the per-read kernel."""
+    import threading
+    key = (torch.cuda.current_device(), threading.get_ident())
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=key[0])
+    return _SIDE[key]
 
 
 def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, early=None):
@@ -170,6 +189,8 @@ def _finalize_mode1(ctx, dist, torch, group, copy):
 
 def allreduce_min_int(value, dist, torch, group=None, device="cuda"):
     """MIN over the ranks of one host integer (RefTime of a FASTQ-only run: the earliest start time of the job)."""
+    if _gloo(dist, group):
+        device = "cpu"                                 # see _all_reduce
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     return int(t.item())

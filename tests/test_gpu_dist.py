@@ -158,3 +158,181 @@ def test_two_ranks_on_one_gpu_over_gloo():
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         open(os.path.join(root, "gpurun_out", "dist_rehearsal_fail.log"), "w").write(r.stdout + "\n---- stderr\n" + r.stderr)
     assert r.returncode == 0 and "dist rehearsal ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def _device_job(torch, qc, synth, ctx, n_reads, mu, n_channels, hours, seed, tweak_times=False):
+    """A synthetic job resident in HBM: (lens, off, device arrays) -- bytes from the HBM generator, metadata from numpy."""
+    lens = synth.read_lengths(n_reads, mu, 1.1774, seed)
+    off = synth.offsets_from_lengths(lens)
+    nb = int(off[-1])
+    ch, mux, t = synth.metadata(n_reads, n_channels, hours, seed)
+    if tweak_times:
+        t = t.copy()
+        t[::17] = t[0]                                    # ties, some at a channel's earliest start
+        t[5::29] = np.iinfo(np.int64).min                 # reads without a start time
+    tb = torch.empty(nb + 64, dtype=torch.uint8, device="cuda")
+    tq = torch.empty(nb + 64, dtype=torch.uint8, device="cuda")
+    ctx.synth_fill_device(tb.data_ptr(), tq.data_ptr(), 0, nb, seed)
+    d_off = torch.from_numpy(off.view(np.int64)).cuda()
+    d_ch, d_mux, d_t = (torch.from_numpy(x).cuda() for x in (ch.view(np.int32), mux, t))
+    ctx.sync()
+    torch.cuda.synchronize()
+    return dict(lens=lens, off=off, nb=nb, R=n_reads, tb=tb, tq=tq, d_off=d_off, d_ch=d_ch, d_mux=d_mux, d_t=d_t,
+                ch=ch, mux=mux, t=t)
+
+
+def _submit_shard(torch, ctx, job, a, e, keep):
+    """Reads [a, e) of a device-resident job as one device batch (off[a] must be a multiple of 16)."""
+    off = job["off"]
+    if e == a:
+        return                                            # an empty shard submits nothing
+    b0 = int(off[a])
+    assert b0 % 16 == 0
+    so = torch.from_numpy((off[a:e + 1] - off[a]).view(np.int64)).cuda()
+    keep.append(so)
+    if True:
+        ctx.submit_device(e - a, int(off[e]) - b0, job["tb"].data_ptr() + b0, job["tq"].data_ptr() + b0, so.data_ptr(),
+                          job["d_ch"].data_ptr() + 4 * a, job["d_mux"].data_ptr() + a, job["d_t"].data_ptr() + 8 * a)
+
+
+FLOWS = (("early", 0, {}), ("phased", 0, dict(early=False)), ("gather", 0, dict(n50="gather")), ("time_mode 1", 1, {}))
+SLEEP_CYCLES = 40_000_000     # torch.cuda._sleep: the stream is held while the host enqueues the whole chain behind it
+
+
+def _nccl_group_of_one(torch, dist):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+
+
+def _snapshot_flow(torch, dist, label, mode, kw):
+    """One merge flow on torch's current stream: the snapshots of a run whose chain is enqueued behind a sleep kernel
+    against those of a run that synchronises the device in front of every collective.  Returns (tables equal, number of
+    collectives, indices of the collectives whose snapshots differ, issuing streams)."""
+    from pypore_amd import qc, synth
+    from pypore_amd.merge import finalize_distributed
+    from stream_collectives import SpyDist
+    cfg = dict(n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=mode, tz_offset_s=0,
+               ref_time_s=1_528_000_000, fail_q=7.0, max_reads_hint=400_000)
+    with qc.QCContext(device=0, **cfg) as ctx:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        job = _device_job(torch, qc, synth, ctx, 400_000, 7.3, 512, 47, 77, tweak_times=mode == 1)
+        other = _device_job(torch, qc, synth, ctx, 150_000, 6.0, 512, 30, 78)
+        assert 2 * job["nb"] > 1_000_000_000
+
+        def run(j, spy, sleep):
+            ctx.reset()
+            if sleep:
+                torch.cuda._sleep(SLEEP_CYCLES)
+            ctx.submit_device(j["R"], j["nb"], j["tb"].data_ptr(), j["tq"].data_ptr(), j["d_off"].data_ptr(),
+                              j["d_ch"].data_ptr(), j["d_mux"].data_ptr(), j["d_t"].data_ptr())
+            return finalize_distributed(ctx, spy, torch, **kw)
+
+        ref = SpyDist(dist, torch, drain=True)
+        want = run(job, ref, False)
+        run(other, SpyDist(dist, torch, drain=True), False)     # leaves another job's values in every buffer
+        spy = SpyDist(dist, torch)
+        got = run(job, spy, True)
+        try:
+            assert_tables_equal(got, want, label)
+            same = True
+        except AssertionError:
+            same = False
+        assert len(spy.snaps) == len(ref.snaps) and [a for a, _ in spy.snaps] == [b for b, _ in ref.snaps]
+        bad = [k for k, ((_, a), (_, b)) in enumerate(zip(spy.snaps, ref.snaps)) if not torch.equal(a, b)]
+        return same, len(spy.snaps), bad, {a for a, _ in spy.snaps}
+
+
+def test_every_collective_finds_its_producers_in_stream_order():
+    """The stream-order contract of DESIGN section 5, checked without any host drain: in front of every collective of
+    finalize_distributed a device-side snapshot of its tensor is enqueued on the stream the collective is issued on
+    (SpyDist), while the context's stream is held by a sleep kernel in front of a 1.2 GB batch -- so the whole chain
+    (per-read kernels, index kernels on the auxiliary stream, phases, collectives, snapshots) is enqueued before any of
+    it runs, and a producer that is not ordered in front of its collective leaves a snapshot of the previous run's
+    (different) job.  Every snapshot must equal the one of a run that synchronises the device in front of each
+    collective.  Early, phased, gather and time_mode 1 merges, on torch's default stream and on a stream of its own;
+    and the check itself is checked: with ppqc_stream_wait_index taken out, the early flow must be caught."""
+    import torch
+    import torch.distributed as dist
+    from pypore_amd import qc
+    _nccl_group_of_one(torch, dist)
+    try:
+        for own_stream in (False, True):
+            with torch.cuda.stream(torch.cuda.Stream() if own_stream else torch.cuda.current_stream()):
+                for label, mode, kw in FLOWS:
+                    same, n, bad, streams = _snapshot_flow(torch, dist, label, mode, kw)
+                    assert same and n >= 2 and not bad, \
+                        "%s (own stream %s): collectives %s of %d found tensors their producers had not finished" % (
+                            label, own_stream, bad, n)
+                    assert len(streams) == (2 if label == "early" else 1)   # early: side-stream collectives + the table SUM
+        keep = qc.QCContext.stream_wait_index
+        qc.QCContext.stream_wait_index = lambda self, handle: None          # negative control: a wait that is missing
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                same, n, bad, _ = _snapshot_flow(torch, dist, *FLOWS[0])
+        finally:
+            qc.QCContext.stream_wait_index = keep
+        assert bad and 0 in bad, "the snapshot check did not notice a missing wait (%s of %d)" % (bad, n)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_in_one_process_stream_ordered(c_oracle):
+    """world_size 2 with no host drain anywhere: two threads drive one context each on streams of their own, and the
+    collectives between them are carried out in stream order on a communication stream (LocalStreamWorld), with each
+    rank's stream held by a sleep kernel while its chain is enqueued.  ONE job cut in two contiguous shards (and an
+    empty shard on one rank), every merge flow, against one context over the whole job."""
+    import threading
+    import torch
+    from pypore_amd import qc, synth
+    from pypore_amd.merge import finalize_distributed
+    from stream_collectives import LocalStreamWorld
+    torch.cuda.set_device(0)
+    for label, mode, kw in FLOWS:
+        cfg = dict(n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=mode, tz_offset_s=-18000 * mode,
+                   ref_time_s=1_528_000_000, fail_q=7.0)
+        with qc.QCContext(device=0, **cfg) as whole:
+            job = _device_job(torch, qc, synth, whole, 300_000, 7.0, 512, 60 if mode else 47, 90 + mode, tweak_times=mode == 1)
+            keep = []
+            _submit_shard(torch, whole, job, 0, job["R"], keep)
+            want = whole.finalize()
+        cut = job["R"] // 3
+        while int(job["off"][cut]) % 16:
+            cut += 1
+        for cuts in ([0, cut, job["R"]], [0, job["R"], job["R"]]):
+            world = LocalStreamWorld(2, torch)
+            got, errors = [None, None], []
+
+            def rank_main(r):
+                try:
+                    torch.cuda.set_device(0)
+                    with torch.cuda.stream(torch.cuda.Stream()):
+                        with qc.QCContext(device=0, **cfg) as ctx:
+                            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                            mine = []
+                            for rep in range(2):          # the second pass finds every buffer allocated: no host wait in it
+                                ctx.reset()
+                                if rep:
+                                    torch.cuda._sleep(SLEEP_CYCLES)
+                                _submit_shard(torch, ctx, job, cuts[r], cuts[r + 1], mine)
+                                got[r] = finalize_distributed(ctx, world.rank(r), torch, **kw)
+                except BaseException as e:      # the other rank would wait at the barrier for ever
+                    errors.append((r, e))
+                    world.bar.abort()
+
+            th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join(120)
+            assert not errors, errors
+            assert not any(x.is_alive() for x in th)
+            assert world.calls >= 4
+            for r in range(2):
+                assert_tables_equal(got[r], want, "%s, rank %d of cuts %s" % (label, r, cuts))
+        if mode == 0:
+            assert want["n50"] == c_oracle.n50(np.asarray(job["lens"]))
