@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PPQC_ABI_VERSION 6
+#define PPQC_ABI_VERSION 7
 
 enum {
     PPQC_OK = 0,
@@ -93,8 +93,8 @@ typedef struct ppqc_config {
  * and its fail counts once per mux.  With this bit the tables of such channels say what the reference says:
  * chan_fail = n_mux * fail, cmh_reads / cmh_bases = (1, length) at the read's hour bin under every mux, and hour_reads /
  * hour_bases (the sum over channels and muxes, lib/seq_routines.py:103-108) count the read n_mux times.  The totals are
- * not changed.  Multi-GPU: like time_mode 1 it needs all reads of a channel on one rank.  The single-read worker
- * (lib/fast5_reader.py:130-145) has no such branch. */
+ * not changed.  Multi-GPU: the rule looks at a channel's read count in the whole job (ppqc_compat_dist_count below).
+ * The single-read worker (lib/fast5_reader.py:130-145) has no such branch. */
 #define PPQC_COMPAT_MULTI_READ_SINGLE 1u
 
 /* One CSR batch of reads (what lib/fast5_reader.py:36-71 / lib/multi_read_fast5_reader.py:89-119
@@ -328,13 +328,29 @@ typedef struct ppqc_mode1_tables {
 int ppqc_mode1_dist_view(ppqc_ctx* ctx, ppqc_mode1_tables* out);
 int ppqc_mode1_dist_phase(ppqc_ctx* ctx, int phase);
 
+/* PPQC_COMPAT_MULTI_READ_SINGLE when a job's reads are spread over several GPUs: `len(l) > 1` of channel_parser
+ * (lib/multi_read_fast5_reader.py:64) is the channel's read count in the whole job.  Between ppqc_finalize_extremes and
+ * ppqc_finalize_tables, ppqc_compat_dist_count counts this context's reads per channel into a device array of n_channels
+ * uint64 (returned in *counts / *n; enqueued on the context's stream); the caller all-reduces it (SUM), and
+ * ppqc_finalize_tables then applies the rule to the channels whose merged count is one -- such a channel's only read is
+ * on one rank, whose rewritten cells the table all-reduce adds to zeros.  Without this call (one GPU) the context's own
+ * channel table is the job's.  ppqc_group_finalize does it by itself. */
+int ppqc_compat_dist_count(ppqc_ctx* ctx, void** counts, uint64_t* n);
+
+/* Makes the context's GPU the calling thread's current device.  For loader threads that call ppqc_alloc_pinned /
+ * ppqc_free_pinned (hipHostMalloc initialises the CURRENT device of the calling thread, device 0 for a fresh thread,
+ * whichever GPU the context lives on).  The reference's counterpart is a worker process inheriting its parent's
+ * state at fork (lib/seq_routines.py:916-923). */
+int ppqc_bind_thread(ppqc_ctx* ctx);
+
 /* Several GPUs driven by ONE process, without torch: the counterpart of gathering the workers' results over the result
  * queue and summing over channels (lib/seq_routines.py:940-942, :103-108) for a caller that binds this library through
  * ctypes / cgo / JNI and has no collective library of its own.  ppqc_group_create takes n contexts on n different GPUs
  * and opens an RCCL communicator over them (ncclCommInitAll; librccl is loaded with dlopen at this call, so the
  * library itself has no link-time dependency on it: PPQC_E_NO_DEVICE if it cannot be loaded).  ppqc_group_finalize runs
  * the phased finalize on every context with the all-reduces in between -- MAX over [max_buf | min_buf], in time_mode 1
- * the three merges of ppqc_mode1_dist_phase, SUM over [sum_buf | sel_buf] and the two further N50-select rounds --
+ * the three merges of ppqc_mode1_dist_phase, with PPQC_COMPAT_MULTI_READ_SINGLE the channel counts of
+ * ppqc_compat_dist_count, SUM over [sum_buf | sel_buf] and the two further N50-select rounds --
  * each on its context's stream, and fetches the merged tables (the same on every context) from the first one.
  * One process per GPU over torch.distributed is the other way (pypore_amd/merge.py); both enqueue the same kernels. */
 typedef struct ppqc_group ppqc_group;

@@ -88,7 +88,9 @@ struct EvPair {
 //   res_busy      every finalize phase (mark_busy)            ppqc_sync (and all that call it)              finalize_extremes
 //   sum_fetched   ppqc_finalize's early result copy           finalize_extremes, fetch_tables                fetch_tables (no second copy; N50 from the
 //                                                                                                           mirror's spare word)
-//   m1_phase      ppqc_mode1_dist_phase (0, 1, 2 in order)    finalize_extremes (-1)                        finalize_tables (2: hours are done)
+//   m1_phase      ppqc_mode1_dist_phase (0, 1, 2 in order)    finalize_extremes (-1), a reference time      finalize_tables (2: hours are done)
+//                                                              that changes (-1: the hours are stale)
+//   cc_ready      ppqc_compat_dist_count                      finalize_extremes                             finalize_tables (job-wide channel counts)
 //   fin_pending / end_split / fin_start / sort_start / sort_end: timing bookkeeping only (resolve_finalize_timings).
 //
 // tests/test_gpu_sequences.py drives random interleavings of every entry point against the oracle; any flag read before it
@@ -163,6 +165,8 @@ struct ppqc_ctx {
     uint64_t* maxlen_host = nullptr;   // a few pinned scratch words (line count of the GPU tokenizer)
     uint64_t* m1 = nullptr;            // time_mode 1 across ranks: [first | ties | days] (ppqc_mode1_dist_view)
     int m1_phase = -1;                 // last phase of ppqc_mode1_dist_phase run since ppqc_finalize_extremes (2: hours done)
+    uint64_t* cc = nullptr;            // PPQC_COMPAT_MULTI_READ_SINGLE across ranks: reads per channel (ppqc_compat_dist_count)
+    bool cc_ready = false;             // ... counted since ppqc_finalize_extremes: ppqc_finalize_tables takes them as the job's
     ppqc_timing timing{};
 };
 
@@ -329,26 +333,6 @@ static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
             HIPCHK(hipGetSymbolSize(&sym_bytes, HIP_SYMBOL(scratch)));
             if (!p || sym_bytes != kStaticScratchBytes)
                 return fail(PPQC_E_HIP, "static scratch: symbol address / size not as built");
-            if (getenv("PPQC_DEBUG_STATIC")) {   // diagnostics: runtime-validated copies only, no kernel touches p
-                fprintf(stderr, "ppqc: static scratch of device %d at %p, %zu bytes (host stand-in %p)\n", device, (void*)p,
-                        sym_bytes, (void*)scratch);
-                hipPointerAttribute_t at;
-                const hipError_t ea = hipPointerGetAttributes(&at, p);
-                fprintf(stderr, "ppqc: hipPointerGetAttributes -> %s, type %d, device %d\n", hipGetErrorString(ea),
-                        ea == hipSuccess ? (int)at.type : -1, ea == hipSuccess ? at.device : -1);
-                (void)hipGetLastError();
-                unsigned char w[64], r[64];
-                for (int i = 0; i < 64; ++i) w[i] = (unsigned char)(i * 7 + 1);
-                const size_t offs[2] = {0, kStaticScratchBytes - 64};
-                for (size_t o : offs) {
-                    memset(r, 0, sizeof r);
-                    const hipError_t e1 = hipMemcpy(p + o, w, 64, hipMemcpyHostToDevice);
-                    const hipError_t e2 = hipMemcpy(r, p + o, 64, hipMemcpyDeviceToHost);
-                    fprintf(stderr, "ppqc: copy round trip at +%zu: %s / %s, %s\n", o, hipGetErrorString(e1),
-                            hipGetErrorString(e2), memcmp(w, r, 64) == 0 ? "same" : "DIFFERENT");
-                }
-                fflush(stderr);
-            }
             g_static_scratch[device] = p;
         }
     }
@@ -459,7 +443,7 @@ int ppqc_destroy(ppqc_ctx* c) {
     void* ptrs[] = {r.rec_cnt, r.rec_hi, r.rec_lo, r.len, r.gc, r.nn, r.qsum, r.mean_q, r.err_hi, r.err_lo, r.flags,
                     r.channel, r.mux, r.time, r.hour, r.lens32, c->head, c->tail, c->res_buf, c->sk32, c->sk32_tmp, c->counts, c->vals, c->vals_tmp, c->sk64,
                     c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev, c->dense.base, c->fq.counts, c->fq.n_entries, c->fq.entries, c->fq.prefix,
-                    c->fq.block_sums, c->fq.line_off, c->fq.span_sum, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo, c->m1};
+                    c->fq.block_sums, c->fq.line_off, c->fq.span_sum, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo, c->m1, c->cc};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->maxlen_host) (void)hipHostFree(c->maxlen_host);
@@ -910,6 +894,7 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     c->fin_gen = c->reads_gen;
     c->sum_fetched = false;
     c->m1_phase = -1;
+    c->cc_ready = false;
     // The result buffer is cleared on the auxiliary stream: this call is usually enqueued while the per-read kernels of
     // the batch still run, and nothing before the extremes kernel touches the results, so the clear costs no time on
     // the main stream.  If an earlier finalize phase may still be running (no synchronisation since), it stays in line.
@@ -959,6 +944,8 @@ int ppqc_time_range(ppqc_ctx* c, int64_t* out2) {
 int ppqc_set_ref_time(ppqc_ctx* c, int64_t ref_time) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     if (c->n_reads && ref_time != c->tp.ref_time_s) c->pre_ok = false;   // hours of the submitted batches are stale
+    if (ref_time != c->tp.ref_time_s) c->m1_phase = -1;   // ... and so are the per-day tables and hours of ppqc_mode1_dist_phase:
+                                                          // ppqc_finalize_tables takes the sort path unless the phases run again
     c->cfg.ref_time_s = ref_time;
     c->tp.ref_time_s = ref_time;
     return PPQC_OK;
@@ -986,15 +973,18 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
         uint64_t span = 0;
         if (tmm[0] <= tmm[1]) {
             span = (uint64_t)tmm[1] - (uint64_t)tmm[0];
-            if (span >= (1ull << 40)) return fail(PPQC_E_RANGE, "time_mode 1: start times span 2^40 ticks or more");
+            // 2^40 - 1 is the key of a read without a start time (mode1_keys_kernel): every timed key must stay below it
+            if (span >= (1ull << 40) - 1) return fail(PPQC_E_RANGE, "time_mode 1: start times span 2^40 ticks or more");
         }
         CHK(ensure_sort64(c, n));
         HIPCHK(launch_mode1_keys(c->ra, n, c->tp, c->tminmax, c->sk64, c->vals, s));
-        const uint32_t mask = (bytes_mask_for(span) & 0x1Fu) | ((bytes_mask_for((uint64_t)c->cfg.n_channels + 1) & 0x7u) << 5);
+        // the bytes of span + 1: in the bytes sorted on, the key of a read without a start time (all ones) then lies above
+        // every timed key of its channel, whatever the span (with the bytes of `span` alone a span of 2^(8k) - 1 tied them)
+        const uint32_t mask = (bytes_mask_for(span + 1) & 0x1Fu) | ((bytes_mask_for((uint64_t)c->cfg.n_channels + 1) & 0x7u) << 5);
         HIPCHK(sort_u64_pairs(c->sk64, c->sk64_tmp, c->vals, c->vals_tmp, n, c->counts, mask, s));
         HIPCHK(launch_mode1_hours(c->ra, n, c->tp, c->sk64, c->vals, c->chan_start, c->first_desc, s));
     }
-    HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, c->max_buf, s));
+    HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, c->max_buf, s, c->cc_ready ? c->cc : nullptr));
     c->state = 2;
     if (c->n50_early) {   // the N50 is there already (ppqc_n50_select_early): the finalize ends here
         HIPCHK(hipEventRecord(c->ev_t1, s));
@@ -1246,6 +1236,27 @@ int ppqc_mode1_dist_phase(ppqc_ctx* c, int phase) {
     return mark_busy(c);
 }
 
+int ppqc_compat_dist_count(ppqc_ctx* c, void** counts, uint64_t* n) {
+    if (!c || !counts || !n) return fail(PPQC_E_INVALID, "null argument");
+    if (!(c->cfg.compat_flags & PPQC_COMPAT_MULTI_READ_SINGLE))
+        return fail(PPQC_E_STATE, "ppqc_compat_dist_count: the context was created without PPQC_COMPAT_MULTI_READ_SINGLE");
+    if (c->state < 1) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes first");
+    if (c->state >= 2) return fail(PPQC_E_STATE, "ppqc_compat_dist_count comes before ppqc_finalize_tables");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->cc) HIPCHK(hipMalloc((void**)&c->cc, (uint64_t)c->cfg.n_channels * 8 + 64));
+    HIPCHK(launch_chan_count(c->ra, c->n_reads, c->cfg.n_channels, c->cc, c->stream));
+    c->cc_ready = true;
+    *counts = c->cc;
+    *n = c->cfg.n_channels;
+    return mark_busy(c);
+}
+
+int ppqc_bind_thread(ppqc_ctx* c) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    return PPQC_OK;
+}
+
 // ---- one process, several GPUs: RCCL through dlopen ---------------------------------------------------------------------
 namespace {
 typedef void* nccl_comm;
@@ -1303,6 +1314,7 @@ static uint64_t* at_maxmin(ppqc_ctx* c, uint64_t) { return c->max_buf; }
 static uint64_t* at_sum(ppqc_ctx* c, uint64_t) { return c->sum_buf; }
 static uint64_t* at_sel(ppqc_ctx* c, uint64_t) { return c->sel_buf; }
 static uint64_t* at_m1(ppqc_ctx* c, uint64_t off) { return c->m1 + off; }
+static uint64_t* at_cc(ppqc_ctx* c, uint64_t) { return c->cc; }
 static int group_all_reduce(ppqc_group* g, group_where where, uint64_t off, uint64_t count, int op) {
     if (count == 0) return PPQC_OK;
     NCCLCHK(g_rccl.GroupStart());
@@ -1374,6 +1386,10 @@ int ppqc_group_finalize(ppqc_group* g, ppqc_tables* out) {
         CHK(group_all_reduce(g, at_m1, nch, nch + 1, kNcclSum));
         CHK(group_all_reduce(g, at_m1, 2 * nch + 1, 2 * nch * PPQC_MODE1_DAYS, kNcclMax));
         for (ppqc_ctx* c : g->ctx) CHK(ppqc_mode1_dist_phase(c, 2));
+    }
+    if (g->ctx[0]->cfg.compat_flags & PPQC_COMPAT_MULTI_READ_SINGLE) {   // a channel's read count in the whole job
+        for (ppqc_ctx* c : g->ctx) { void* p; uint64_t k; CHK(ppqc_compat_dist_count(c, &p, &k)); }
+        CHK(group_all_reduce(g, at_cc, 0, nch, kNcclSum));
     }
     for (ppqc_ctx* c : g->ctx) CHK(ppqc_finalize_tables(c));
     for (int r = 0; r < 3; ++r) {

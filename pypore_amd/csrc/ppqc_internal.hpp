@@ -101,8 +101,11 @@ hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uin
 hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays ra, const TableParams& tp,
                                  uint64_t* max_buf, uint64_t* min_buf, int64_t* tminmax, uint64_t* bound,
                                  uint64_t* bound_host, hipStream_t s);   // at submit time, beside the tile kernel
+// job_chan_count: per-channel read count of the whole multi-GPU job for PPQC_COMPAT_MULTI_READ_SINGLE (nullptr: this
+// rank's own table is the job's)
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
-                         hipStream_t s);
+                         hipStream_t s, const uint64_t* job_chan_count = nullptr);
+hipError_t launch_chan_count(ReadArrays ra, uint64_t n, uint32_t n_channels, uint64_t* out, hipStream_t s);
 
 hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s);
 // res = [n_zero sums (tables + select histogram) = 0 | nch1 max = 0 | nch1 ~min = ~INT64_MAX | tmin = INT64_MAX,

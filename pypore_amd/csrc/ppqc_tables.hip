@@ -145,13 +145,18 @@ __global__ __launch_bounds__(256) void cmh_unpack_kernel(uint64_t* sum_buf, Tabl
 // pass over the reads behind tables_kernel / cmh_unpack_kernel: a read whose channel counted one read is that channel's
 // only contributor, so its thread rewrites the channel's cells with plain stores and tops up the hour totals (the sum
 // over channels and muxes of lib/seq_routines.py:103-108) by what the normal rule did not give them.
-__global__ __launch_bounds__(256) void compat_single_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf) {
+//
+// `job_count` (ppqc_compat_dist_count): the channel's read count over ALL ranks of a multi-GPU job.  A read whose channel
+// counts one read in the whole job is on this rank alone, so the same stores apply, and the table SUM that follows adds
+// the rewritten cells to the zeros of the other ranks.  nullptr: one rank, the local table is the job's.
+__global__ __launch_bounds__(256) void compat_single_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf,
+                                                            const uint64_t* __restrict__ job_count) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t chn = ra.channel[i], nch = tp.lay.n_channels, nmux = tp.lay.n_mux, nb = tp.lay.n_time_bins;
     if (chn < 1 || chn > nch) return;
     const uint32_t c = chn - 1;
-    if (sum_buf[tp.lay.off_chan_reads + c] != 1) return;
+    if ((job_count ? job_count[c] : sum_buf[tp.lay.off_chan_reads + c]) != 1) return;
     const uint64_t L = ra.len[i], fail = ra.flags[i] & 1u;
     sum_buf[tp.lay.off_chan_fail + c] = (uint64_t)nmux * fail;          // `FailedReads += 1` once per mux (:69-70)
     const int32_t h = ra.hour[i];
@@ -166,6 +171,16 @@ __global__ __launch_bounds__(256) void compat_single_kernel(ReadArrays ra, uint6
     if (extra) {
         atomicAdd((unsigned long long*)&sum_buf[tp.lay.off_hour_reads + h], (unsigned long long)extra);
         atomicAdd((unsigned long long*)&sum_buf[tp.lay.off_hour_bases + h], (unsigned long long)(extra * L));
+    }
+}
+
+// Reads per channel of this rank (ReadPerChannel = len(l), lib/multi_read_fast5_reader.py:50), before the tables exist:
+// what the ranks of a job add up to apply the rule above (ppqc_compat_dist_count).  `out` is cleared by the launcher.
+__global__ __launch_bounds__(256) void chan_count_kernel(const uint32_t* __restrict__ channel, uint64_t n, uint32_t nch,
+                                                         uint64_t* out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t ch = channel[i];
+        if (ch >= 1 && ch <= nch) atomicAdd((unsigned long long*)&out[ch - 1], 1ull);
     }
 }
 
@@ -440,8 +455,15 @@ hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays r
     return hipGetLastError();
 }
 
+hipError_t launch_chan_count(ReadArrays ra, uint64_t n, uint32_t n_channels, uint64_t* out, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)n_channels * 8, s);
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(chan_count_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, s, ra.channel, n, n_channels, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
-                         hipStream_t s) {
+                         hipStream_t s, const uint64_t* job_chan_count) {
     if (n == 0) return hipSuccess;
     const uint32_t nb = tp.lay.n_time_bins;
     // per-channel accumulators in LDS need 16 B per channel; keep the block under 64 KiB so 2 blocks fit a CU.  When
@@ -462,7 +484,8 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
     const uint64_t cells = (uint64_t)tp.lay.n_channels * tp.lay.n_mux * tp.lay.n_time_bins;
     hipLaunchKernelGGL(cmh_unpack_kernel, dim3(grid_for(cells, 512)), dim3(256), 0, s, sum_buf, tp.lay, n, max_buf);
     if (tp.compat_flags & PPQC_COMPAT_MULTI_READ_SINGLE)
-        hipLaunchKernelGGL(compat_single_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ra, n, tp, sum_buf);
+        hipLaunchKernelGGL(compat_single_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ra, n, tp, sum_buf,
+                           job_chan_count);
     return hipGetLastError();
 }
 
@@ -537,7 +560,7 @@ __global__ __launch_bounds__(256) void mode1d_days_kernel(ReadArrays ra, uint64_
 }
 
 // one thread per channel: first[ch] <- T* (INT64_MAX: no read of the channel is bumped)
-__global__ __launch_bounds__(256) void mode1d_pick_kernel(TableParams tp, int64_t* first, const uint64_t* __restrict__ ties,
+__global__ __launch_bounds__(256) void mode1d_pick_kernel(TableParams tp, int64_t* first, uint64_t* ties,
                                                           const int64_t* __restrict__ dmax, const int64_t* __restrict__ dmin) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= tp.lay.n_channels) return;
@@ -546,7 +569,11 @@ __global__ __launch_bounds__(256) void mode1d_pick_kernel(TableParams tp, int64_
     if (f != INT64_MIN) {   // the channel has a timed read
         const int64_t t0 = ~f;
         const bool t0_in_s = ties[c] >= 2;
-        const int64_t d0 = mode1_day(t0, tp);   // may lie outside the window: then it matches no d below (and the run fails)
+        const int64_t d0 = mode1_day(t0, tp);
+        // Several reads tied at t0: all but one belong to S, and S's day tables have no entry outside the window -- the
+        // run fails like for any other read of S out there (every rank sees the same merged tables and counts the same).
+        // A lone first read outside the window is in no table and needs none.
+        if (t0_in_s && (d0 < 0 || d0 >= kMode1Days)) atomicAdd((unsigned long long*)&ties[tp.lay.n_channels], 1ull);
         int32_t m = -1;
         for (int d = 0; d < kMode1Days; ++d) {
             int64_t mx = dmax[(uint64_t)c * kMode1Days + d], mn = ~dmin[(uint64_t)c * kMode1Days + d];

@@ -123,11 +123,15 @@ def channel_path_checks(files, h5_open=None):
     return out
 
 
-def iter_record_batches(files, n_channels=512, threads=1, h5_open=None, batch_reads=4000):
+def iter_record_batches(files, n_channels=512, threads=1, h5_open=None, batch_reads=4000, job_files=None):
     """Lists of loader records ``(channel, mux, start_time, fail, title, bases, quals)``, ``batch_reads`` files at a
     time.  Unreadable reads are skipped as in the reference's ``except: del ds`` (lib/fast5_reader.py:104-116); a file
-    name without a channel field raises like :910."""
-    checks = channel_path_checks(files, h5_open)
+    name without a channel field raises like :910.  ``job_files``: all files of the job when ``files`` is one rank's
+    share of them -- the probe file of a channel is picked among the job's files, so that every rank (and a run on one
+    GPU, and the reference) hands the same group names to the channel's reads."""
+    mine = {channel_of(f) for f in files}
+    checks = channel_path_checks([f for f in (job_files if job_files is not None else files) if channel_of(f) in mine],
+                                 h5_open)
 
     def one(f):
         ch = channel_of(f)

@@ -77,6 +77,14 @@ def _all_reduce(dist, torch, t, op, group=None):
     dist.all_reduce(t, op=op, group=group)
 
 
+def _merge_compat_counts(ctx, dist, torch, group):
+    """PPQC_COMPAT_MULTI_READ_SINGLE (channel_parser's ``len(l) > 1``, lib/multi_read_fast5_reader.py:64): the rule looks at
+    a channel's read count in the whole job, so the ranks add their counts up before the tables are built."""
+    from ._lib import COMPAT_MULTI_READ_SINGLE
+    if ctx.cfg.compat_flags & COMPAT_MULTI_READ_SINGLE:
+        _all_reduce(dist, torch, torch.as_tensor(ctx.compat_dist_count(), device="cuda"), dist.ReduceOp.SUM, group)
+
+
 _SIDE = {}
 
 
@@ -126,6 +134,7 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, 
                 ctx.n50_select_early(r, 1, side.cuda_stream)
         torch.cuda.current_stream().wait_stream(side)
         ctx.finalize_extremes()
+        _merge_compat_counts(ctx, dist, torch, group)
         ctx.finalize_tables()                    # uses the merged max_len; the N50 is final already
         t_sum = torch.as_tensor(views["sum"], device="cuda")
         _all_reduce(dist, torch, t_sum, dist.ReduceOp.SUM, group)
@@ -135,6 +144,7 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, 
     # the device keeps the minima complemented, so maxima and minima merge in ONE all-reduce(MAX)
     t_maxmin = torch.as_tensor(views["maxmin"], device="cuda")
     _all_reduce(dist, torch, t_maxmin, dist.ReduceOp.MAX, group)
+    _merge_compat_counts(ctx, dist, torch, group)
     ctx.finalize_tables()                        # length histogram bins use the merged max_len
     if n50 == "select":
         t_sum_sel = torch.as_tensor(views["sum_sel"], device="cuda")
@@ -174,6 +184,7 @@ def _finalize_mode1(ctx, dist, torch, group, copy):
     _all_reduce(dist, torch, torch.as_tensor(m1["ties"], device="cuda"), dist.ReduceOp.SUM, group)
     _all_reduce(dist, torch, torch.as_tensor(m1["days"], device="cuda"), dist.ReduceOp.MAX, group)
     ctx.mode1_dist_phase(2)
+    _merge_compat_counts(ctx, dist, torch, group)
     ctx.finalize_tables()
     t_sum_sel = torch.as_tensor(views["sum_sel"], device="cuda")
     t_sel = torch.as_tensor(views["sel"], device="cuda")
@@ -245,6 +256,8 @@ def mode1_hours_reference(channel, time, cfg, all_reduce_max, all_reduce_sum):
             continue
         t0 = int(~first[c])
         d0, m = int(day(t0)), -1
+        if ties[c] >= 2 and not 0 <= d0 < MODE1_DAYS:          # reads of S at t0 that the day tables cannot hold
+            ties[nch] += 1
         for dd in range(MODE1_DAYS):
             mx, mn = int(dmax[c * MODE1_DAYS + dd]), int(~dmin[c * MODE1_DAYS + dd])
             any_ = mx != NONE
@@ -262,6 +275,30 @@ def mode1_hours_reference(channel, time, cfg, all_reduce_max, all_reduce_sum):
     h = hod(t[ok]) + np.where(t[ok] >= tstar[ch[ok] - 1], 24, 0)
     hours[ok] = np.where(h < nb, h, -1)
     return hours, int(ties[nch])
+
+
+def compat_single_reference(tables, channel, mux, length, fail, hour, job_count, cfg):
+    """The arithmetic of compat_single_kernel with ppqc_compat_dist_count on host arrays (tests): ``tables`` are this
+    rank's tables built WITHOUT the rule from its own reads (``channel`` .. ``hour`` per read), ``job_count`` the
+    all-reduced reads per channel.  A channel that holds one read in the whole job has it on one rank: that rank
+    rewrites the channel's cells (chan_fail = n_mux * fail, (1, length) under every mux at the read's hour) and tops up
+    the hour totals; summed over the ranks the tables are those of channel_parser on the whole job
+    (lib/multi_read_fast5_reader.py:64-70).  In place."""
+    nch, nmux, nb = int(cfg["n_channels"]), int(cfg["n_mux"]), int(cfg["n_time_bins"])
+    for i in range(len(channel)):
+        c = int(channel[i]) - 1
+        if c < 0 or c >= nch or int(job_count[c]) != 1:
+            continue
+        L, h = int(length[i]), int(hour[i])
+        tables["chan_fail"][c] = nmux * int(bool(fail[i]))
+        if h < 0 or h >= nb:
+            continue
+        tables["cmh_reads"][c, :, h] = 1
+        tables["cmh_bases"][c, :, h] = L
+        extra = nmux - (1 if 1 <= int(mux[i]) <= nmux else 0)
+        tables["hour_reads"][h] += extra
+        tables["hour_bases"][h] += extra * L
+    return tables
 
 
 SELECT_ROUNDS = ((21, 11), (10, 11), (0, 10))    # (shift, bits) of ppqc_n50_select_hist / _pick

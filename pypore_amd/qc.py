@@ -328,6 +328,17 @@ class QCContext:
     def mode1_dist_phase(self, phase):
         L.check(self._lib.ppqc_mode1_dist_phase(self._ctx, int(phase)))
 
+    def compat_dist_count(self):
+        """COMPAT_MULTI_READ_SINGLE across ranks: counts this context's reads per channel (between ``finalize_extremes``
+        and ``finalize_tables``) and returns the zero-copy device view (int64) the caller all-reduces with SUM."""
+        p, n = C.c_void_p(), C.c_uint64()
+        L.check(self._lib.ppqc_compat_dist_count(self._ctx, C.byref(p), C.byref(n)))
+        return DeviceArrayView(p.value, n.value, "<i8", self)
+
+    def bind_thread(self):
+        """The context's GPU becomes the calling thread's current device (loader threads that allocate pinned memory)."""
+        L.check(self._lib.ppqc_bind_thread(self._ctx))
+
     def timings(self):
         t = L.Timing()
         L.check(self._lib.ppqc_timings(self._ctx, C.byref(t)))

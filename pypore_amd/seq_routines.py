@@ -756,7 +756,8 @@ def fast5module(work_dir_, file_folder, prefix_, tmp_dir, Fast_flag, size, h5_op
     if ref_time is None:
         log.error("no Fast5 file under %s" % file_folder)
         sys.exit(1)
-    batches = f5r.iter_record_batches(my_share(files), n_channels, threads=size, h5_open=h5_open)
+    # the path check of a channel is made on ONE file of the channel in the whole job, whichever rank reads it
+    batches = f5r.iter_record_batches(my_share(files), n_channels, threads=size, h5_open=h5_open, job_files=files)
     tables, per_read, kept = _tables_from_loader(batches, ref_time, Fast_flag)
     if is_writer():
         for c in np.nonzero(tables["chan_reads"] == 0)[0]:
@@ -783,15 +784,10 @@ def multifast5reader(work_dir_, file_folder, prefix_, tmp_dir, Fast_flag, size, 
     batches = mf5r.iter_record_batches(my_share(files), threads=size, h5_open=h5_open)
     # channel_parser takes the read of a single-read channel under every mux (lib/multi_read_fast5_reader.py:64-67):
     # reproduced, so that the tables are the reference's (PPQC_COMPAT_MULTI_READ_SINGLE; fast5module has no such branch).
-    # The rule looks at a channel's read count in the whole job, which one rank of several does not know: a multi-GPU
-    # run counts such a read under its own mux only and says so.
+    # The rule looks at a channel's read count in the whole job: with several GPUs the ranks add their per-channel
+    # counts up first (merge._merge_compat_counts), so `--gpus N` gives the tables of one GPU.
     from ._lib import COMPAT_MULTI_READ_SINGLE
     compat = COMPAT_MULTI_READ_SINGLE
-    if DIST is not None:
-        compat = 0
-        if is_writer():
-            log.warning("--gpus > 1: the single-read-channel rule of channel_parser (a channel's only read counted under "
-                        "every mux) is not applied; run on one GPU for tables identical to the reference's in that case")
     tables, per_read, kept = _tables_from_loader(batches, ref_start or 0, Fast_flag, compat)
     if is_writer():
         for c in np.nonzero(tables["chan_reads"] == 0)[0]:

@@ -136,6 +136,9 @@ class Stage:
 
         def loader():
             try:
+                # pinned arenas are allocated from this thread: on the context's GPU, not on a fresh thread's device 0
+                if hasattr(self.ctx, "bind_thread"):
+                    self.ctx.bind_thread()
                 while True:
                     # a free slot FIRST, then the next job, both under one lock: the earlier job always has its slot, so
                     # the caller, who takes the items in order, never waits for a job whose loader waits for a slot

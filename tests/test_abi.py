@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), "libpypore_qc.so does not export %s" % n
     assert sorted(_lib.SYMBOLS) == names, "pypore_amd/_lib.py SYMBOLS out of sync with include/pypore_qc.h"
-    assert lib.ppqc_abi_version() == 6
+    assert lib.ppqc_abi_version() == 7
 
 
 def test_ctypes_structs_match_header_layout(lib, tmp_path):

@@ -69,6 +69,28 @@ def _worker(rank, world, port, tmp):
                      [[2_000_000] * 3, list(range(1, 3000))]):
             mine = np.asarray(case[rank], dtype=np.uint32)
             assert merge.n50_select_reference(mine, ar) == po.n50([int(x) for x in case[0] + case[1]]), case
+        # PPQC_COMPAT_MULTI_READ_SINGLE across ranks (merge._merge_compat_counts + compat_single_kernel): per-channel read
+        # counts all-reduced, the rule applied by the rank that holds a single-read channel's read, tables summed
+        cfgc = dict(n_channels=40, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=0, tz_offset_s=0,
+                    ref_time_s=1_528_000_000, fail_q=7.0)
+        bc = random_batch(78, 60, 60, edge=False, n_channels=40, hours=47)
+        Rc = len(bc["channel"])
+        for ca, ce in ([0, Rc // 2, Rc][rank:rank + 2], [0, Rc, Rc][rank:rank + 2]):     # halves; an empty shard on rank 1
+            oc = bc["offsets"][ca:ce + 1]
+            stc = po.per_read_stats(bc["bases"][int(oc[0]):int(oc[-1])], bc["quals"][int(oc[0]):int(oc[-1])], oc - oc[0])
+            mc = (bc["channel"][ca:ce], bc["mux"][ca:ce], bc["time"][ca:ce], bc["fail_flag"][ca:ce])
+            lc = po.build_tables(stc, *mc, cfg=cfgc)
+            cnt = torch.from_numpy(np.asarray(lc["chan_reads"], np.int64).copy())
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            lenc = np.where(mc[3] != 0, 0, stc["length"])
+            merge.compat_single_reference(lc, mc[0], mc[1], lenc, lc["fail"], lc["hour"], cnt.numpy(), cfgc)
+            fullc = po.build_tables(po.per_read_stats(bc["bases"], bc["quals"], bc["offsets"]), bc["channel"], bc["mux"],
+                                    bc["time"], bc["fail_flag"], cfg=dict(cfgc, compat_flags=1))
+            assert int((np.asarray(fullc["chan_reads"]) == 1).sum()) >= 8
+            for k in ("hour_reads", "hour_bases", "chan_reads", "chan_fail", "cmh_reads", "cmh_bases"):
+                tk = torch.from_numpy(np.ascontiguousarray(lc[k], dtype=np.int64).copy())
+                dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+                assert np.array_equal(tk.numpy(), np.asarray(fullc[k])), ("compat across ranks", k)
         hm = merge.merge_tables_host([loc, loc])
         assert np.array_equal(hm["chan_reads"], 2 * np.asarray(loc["chan_reads"]))
         open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")

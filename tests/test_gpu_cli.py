@@ -340,6 +340,44 @@ def test_cli_gpus_2_equals_one_process(tmp_path):
         assert d1 == d2, f
     assert gzip.decompress((tmp_path / "res_s1" / "s1.fastq.gz").read_bytes()) == \
         gzip.decompress((tmp_path / "res_s2" / "s2.fastq.gz").read_bytes())
+    # multi-read Fast5: channel_parser's single-read-channel rule (lib/multi_read_fast5_reader.py:64-67) looks at a channel's
+    # read count in the whole job -- the ranks add their counts up, so two ranks give the tables of one, and both those of
+    # parsing_func(multi_read_single_quirk=True).  240 reads over 512 channels in four files: single-read channels on
+    # either rank, and channels with one read on each
+    mrecs = _records(13, 240, hours=40)
+    (tmp_path / "m" / "pass").mkdir(parents=True)
+    (tmp_path / "m" / "fail").mkdir(parents=True)
+    for r in mrecs:
+        r["fail"] = r["i"] % 7 == 0
+    good = [r for r in mrecs if not r["fail"]]
+    bad = [r for r in mrecs if r["fail"]]
+
+    def entry(r, with_fq):
+        fq = "@read%d\n%s\n+\n%s\n" % (r["i"], r["seq"].decode(), r["qual"].decode()) if with_fq else None
+        return ("read_%04d" % r["i"], r["ch"], r["mux"], _iso(base, r["sec"]), fq)
+    for name, part in (("pass/a", good[:60]), ("pass/b", good[60:130]), ("pass/c", good[130:])):
+        fake_h5.write_multi(str(tmp_path / "m" / (name + ".fast5")), [entry(r, True) for r in part], exp)
+    fake_h5.write_multi(str(tmp_path / "m" / "fail" / "d.fast5"), [entry(r, False) for r in bad], exp)
+    for label, extra in (("m1", []), ("m2", ["--gpus", "2"])):
+        r = _run_cli(["-i", str(tmp_path / "m"), "-l", label, "-m", "yes", "-n", "2", "-o", "res_" + label] + extra,
+                     str(tmp_path), h5)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+        assert "is not applied" not in r.stdout + r.stderr
+    from pypore_amd import seq_routines as sq, fast5_reader as f5r
+    ref_cd_m = _ref_shaped(mrecs, f5r.mktime_local(exp), sq.local_tz_offset(),
+                           times=[int(f5r.mktime_local(_iso(base, r["sec"]))) for r in mrecs], multi_read_single_quirk=True)
+    assert sum(1 for c in range(1, 513) if ref_cd_m[str(c)] and ref_cd_m[str(c)][0] == 1) > 50
+    want_m = po.FastStats_data(ref_cd_m)
+    for f in ("_sequencing_summary.html", "_pore_activity_map.html"):
+        d1, _ = _plot_data(str(tmp_path / "res_m1" / ("m1" + f)))
+        d2, _ = _plot_data(str(tmp_path / "res_m2" / ("m2" + f)))
+        assert d1 == d2, f
+        if f.startswith("_seq"):
+            tr = {t["name"]: t for t in d2 if t.get("name") in ("ReadsPerHour", "BasesPerHour")}
+            assert [int(v) for v in tr["ReadsPerHour"]["y"]] == [v[0] for v in want_m["HoursDict"]]
+            assert [int(v) for v in tr["BasesPerHour"]["y"]] == [v[1] for v in want_m["HoursDict"]]
+            cells = [c[0] if isinstance(c, list) else c for c in [t for t in d2 if t.get("type") == "table"][0]["cells"]["values"]]
+            assert [float(c) for c in cells] == [float(v) for v in want_m["table"]]
     # a rank count the launcher cannot give must fail loudly, not run on fewer ranks
     r = _run_cli(["-i", str(tmp_path / "in"), "-l", "bad", "-f", "fastq", "--gpus", "2"], str(tmp_path),
                  {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})

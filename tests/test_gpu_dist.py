@@ -336,3 +336,112 @@ def test_two_ranks_in_one_process_stream_ordered(c_oracle):
                 assert_tables_equal(got[r], want, "%s, rank %d of cuts %s" % (label, r, cuts))
         if mode == 0:
             assert want["n50"] == c_oracle.n50(np.asarray(job["lens"]))
+
+
+def test_single_read_channel_rule_across_ranks(qc_mod, c_oracle):
+    """PPQC_COMPAT_MULTI_READ_SINGLE with a job's reads on two ranks (lib/multi_read_fast5_reader.py:64-67: `len(l) > 1`
+    is the channel's read count in the whole job): ppqc_compat_dist_count + one small all-reduce SUM in front of the
+    tables.  Two ranks in one process with stream-ordered collectives, every merge flow; cuts that leave single-read
+    channels on either rank, channels with one read on each rank (not single), and an empty shard.  Against one context
+    over the whole job, the oracle's channel_parser restatement, and ppqc_group_finalize on one GPU."""
+    import threading
+    import torch
+    from pypore_amd.merge import finalize_distributed
+    from stream_collectives import LocalStreamWorld
+    qc = qc_mod
+    torch.cuda.set_device(0)
+    for label, mode, kw in FLOWS:
+        cfg = dict(n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=mode, tz_offset_s=3600 * mode,
+                   ref_time_s=1_528_000_000, fail_q=7.0, compat_flags=1)
+        b = random_batch(61 + mode, 700, 150, hours=46)
+        R = len(b["channel"])
+        args = lambda a, e: (b["bases"][int(b["offsets"][a]):int(b["offsets"][e])], b["quals"][int(b["offsets"][a]):int(b["offsets"][e])],
+                             b["offsets"][a:e + 1] - b["offsets"][a], b["channel"][a:e], b["mux"][a:e], b["time"][a:e],
+                             b["fail_flag"][a:e])
+        with qc.QCContext(device=0, **cfg) as whole, qc.QCContext(device=0, **dict(cfg, compat_flags=0)) as plain:
+            whole.submit(*args(0, R))
+            want = whole.finalize()
+            plain.submit(*args(0, R))
+            without = plain.finalize()
+            with qc.Group([whole]) as grp:           # the library's own merge applies the rule too
+                whole.reset()
+                whole.submit(*args(0, R))
+                assert_tables_equal(grp.finalize(), want, "group of one with the single-read-channel rule")
+        w = c_oracle.per_read(b["bases"], b["quals"], b["offsets"], nthreads=4)
+        assert_tables_equal(want, c_oracle.tables(w, b["channel"], b["mux"], b["time"], b["fail_flag"], cfg))
+        assert int((want["chan_reads"] == 1).sum()) > 100 and not np.array_equal(want["cmh_reads"], without["cmh_reads"])
+        for cuts in ([0, R // 3, R], [0, R, R]):
+            world = LocalStreamWorld(2, torch)
+            got, errors = [None, None], []
+
+            def rank_main(r):
+                try:
+                    torch.cuda.set_device(0)
+                    with torch.cuda.stream(torch.cuda.Stream()):
+                        with qc.QCContext(device=0, **cfg) as ctx:
+                            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                            if cuts[r + 1] > cuts[r]:
+                                ctx.submit(*args(cuts[r], cuts[r + 1]))
+                            got[r] = finalize_distributed(ctx, world.rank(r), torch, **kw)
+                except BaseException as e:
+                    errors.append((r, e))
+                    world.bar.abort()
+
+            th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join(120)
+            assert not errors, errors
+            for r in range(2):
+                assert_tables_equal(got[r], want, "%s with the single-read-channel rule, rank %d of cuts %s" % (label, r, cuts))
+
+
+def test_mode1_corner_cases_of_the_review(qc_mod, c_oracle):
+    """(1) reads tied at a channel's earliest start that lies outside the day window fail the run; (2) a read
+    without a start time keeps out of the timed reads' order whatever the span of the start times (a span of 2^8k - 1
+    used to tie its sort key with the latest timed read's); (3) a reference time set behind ppqc_mode1_dist_phase makes
+    ppqc_finalize_tables compute the hours again instead of binning with stale ones."""
+    from pypore_amd._lib import PPQCError
+    qc = qc_mod
+    seq = lambda n: (np.frombuffer(b"ACGT" * n, np.uint8), np.frombuffer(b"IIII" * n, np.uint8),
+                     np.arange(0, 4 * n + 1, 4, dtype=np.uint64))
+    cfg = dict(n_channels=4, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=1, tz_offset_s=0, ref_time_s=10**9)
+    with qc.QCContext(device=0, **cfg) as ctx:
+        ctx.submit(*seq(3), np.array([1, 1, 1], np.uint32), np.array([1, 1, 1], np.uint8),
+                   np.array([10**9 - 86400 * 3, 10**9 - 86400 * 3, 10**9 + 3600], np.int64))
+        ctx.finalize_extremes()
+        for ph in range(3):
+            ctx.mode1_dist_phase(ph)
+        ctx.finalize_tables()
+        ctx.finalize_n50()
+        with pytest.raises(PPQCError, match="day window"):
+            ctx.fetch_tables()
+    # (2) ten-tick bins: 0, 100, 230, 255 ticks are hours 0, 10, 23, 1 -> the last read is bumped to 25
+    cfg2 = dict(n_channels=2, n_mux=4, n_time_bins=48, bin_seconds=10, time_mode=1, tz_offset_s=0, ref_time_s=0, fail_q=7.0)
+    t = np.array([np.iinfo(np.int64).min, 0, 100, 230, 255], np.int64)
+    ch, mux = np.ones(5, np.uint32), np.ones(5, np.uint8)
+    with qc.QCContext(device=0, **cfg2) as ctx:
+        ctx.submit(*seq(5), ch, mux, t)
+        got = ctx.finalize()
+        assert list(ctx.read_hours()) == [-1, 0, 10, 23, 25]
+    b, q, o = seq(5)
+    assert_tables_equal(got, c_oracle.tables(c_oracle.per_read(b, q, o, nthreads=1), ch, mux, t, None, cfg2))
+    # (3)
+    bb = random_batch(71, 3000, 100, n_channels=24, hours=60)
+    cfg3 = dict(n_channels=24, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=1, tz_offset_s=0,
+                ref_time_s=1_528_000_000, fail_q=7.0)
+    args = (bb["bases"], bb["quals"], bb["offsets"], bb["channel"], bb["mux"], bb["time"], bb["fail_flag"])
+    new_ref = 1_528_000_000 - 5 * 3600
+    with qc.QCContext(device=0, **dict(cfg3, ref_time_s=new_ref)) as fresh:
+        fresh.submit(*args)
+        want = fresh.finalize()
+    with qc.QCContext(device=0, **cfg3) as ctx:
+        ctx.submit(*args)
+        ctx.finalize_extremes()
+        for ph in range(3):
+            ctx.mode1_dist_phase(ph)
+        ctx.set_ref_time(new_ref)
+        ctx.finalize_tables()
+        ctx.finalize_n50()
+        assert_tables_equal(ctx.fetch_tables(), want, "reference time set behind the phases")

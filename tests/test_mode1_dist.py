@@ -81,6 +81,11 @@ def test_reads_outside_the_day_window_are_counted():
     t = np.asarray([10**9, 10**9 + 5, 10**9 + 86400 * 70, 10**9 - 86400 * 3], np.int64)
     _, oob = merge.mode1_hours_reference(np.asarray([1, 1, 1, 2]), t, cfg, ident, ident)
     assert oob == 1        # the read 70 days on; the lone early read of channel 2 is that channel's first and has no day
+    # two reads tied at a channel's earliest start, outside the window: one of them belongs to S, whose day tables cannot
+    # hold it -- counted, so the run fails instead of dropping its hour from the prefix maximum
+    t = np.asarray([10**9 - 86400 * 3, 10**9 - 86400 * 3, 10**9 + 3600], np.int64)
+    _, oob = merge.mode1_hours_reference(np.asarray([1, 1, 1]), t, cfg, ident, ident)
+    assert oob == 1
 
 
 def _free_port():
