@@ -73,6 +73,9 @@ def parse(argv=None):
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no GPU work: N ranks over gloo go through the launch, the rendezvous, the barriers and the "
                          "max-over-ranks / sum-over-ranks reporting of this script (the CPU test of the launcher path)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
+                    help="A/B runs: ppqc_set_tuning on every context of this run (e.g. tile_all=0, fastq_sums=2); results "
+                         "do not depend on it")
     ap.add_argument("--master-port", type=int, default=0, help="launcher: rendezvous port (0 = pick a free one)")
     return ap.parse_args(argv)
 
@@ -234,6 +237,7 @@ def main():
 
     from pypore_amd import qc, synth
     from pypore_amd.merge import finalize_distributed
+    qc.QCContext.DEFAULT_TUNING = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune}
 
     seed = a.seed + 7919 * rank
     if a.workload == "config4adv":

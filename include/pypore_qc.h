@@ -343,6 +343,15 @@ int ppqc_compat_dist_count(ppqc_ctx* ctx, void** counts, uint64_t* n);
  * state at fork (lib/seq_routines.py:916-923). */
 int ppqc_bind_thread(ppqc_ctx* ctx);
 
+/* No counterpart in the reference.  Test and measurement hook: where the library has more than one code path for the
+ * same result (which of the two per-read kernels takes a tile, the tile size, index kernels at submit or at finalize
+ * time, how the GPU FASTQ tokenizer sums its lines), `value` -1 leaves the choice to the library -- the state of every
+ * new context -- and other values force one path for this context: "tile_dense" 0|1, "dense_len" bytes, "tile_all" 0|1,
+ * "tile_shift" 12..16, "pre" 0|1, "fastq_sums" 0|1|2, "fastq_hdr_aux" 0|1|2 (pypore_amd/csrc/ppqc_internal.hpp, Tuning).
+ * Results never depend on it (the parity tests run the paths against each other); the library reads no environment
+ * variable. */
+int ppqc_set_tuning(ppqc_ctx* ctx, const char* name, int value);
+
 /* Several GPUs driven by ONE process, without torch: the counterpart of gathering the workers' results over the result
  * queue and summing over channels (lib/seq_routines.py:940-942, :103-108) for a caller that binds this library through
  * ctypes / cgo / JNI and has no collective library of its own.  ppqc_group_create takes n contexts on n different GPUs

@@ -97,6 +97,7 @@ struct EvPair {
 // is defined on some path shows up there as a table that differs.
 struct ppqc_ctx {
     int device = 0, n_cu = 256;
+    Tuning tn{};   // ppqc_set_tuning: all -1 (the library's own choices) unless a test or a measurement says otherwise
     ppqc_config cfg{};
     TableParams tp{};
     hipStream_t stream = nullptr, own_stream = nullptr, copy[2] = {nullptr, nullptr};
@@ -515,7 +516,7 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     // takes is decided per tile on the device (ppqc_tile.hip), not here.
     uint32_t shift = kDefaultTileShift;
     while (shift > 14 && (b->n_bytes >> shift) < 16384) --shift;
-    if (const char* e = getenv("PPQC_TILE_SHIFT")) shift = (uint32_t)atoi(e);   // tuning knob for A/B runs
+    if (c->tn.tile_shift >= 0) shift = (uint32_t)c->tn.tile_shift;
     if (shift < (uint32_t)kMinTileShift || shift > (uint32_t)kMaxTileShift) shift = kDefaultTileShift;
     const uint64_t n_tiles = (b->n_bytes + (1ull << shift) - 1) >> shift;
     CHK(ensure_tiles(c, n_tiles));
@@ -528,11 +529,10 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     HIPCHK(hipEventRecord(ev.a, s));
     hipEvent_t prev_a = c->last_a;
     c->last_a = ev.a;
-    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->dense, c->n_cu, s));
+    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->dense, c->tn, s));
     HIPCHK(hipEventRecord(ev.b, s));
     c->pending.push_back(ev);
-    static const bool pre_enabled = !(getenv("PPQC_PRE") && atoi(getenv("PPQC_PRE")) == 0);   // A/B knob
-    const bool pre = c->pre_ok && c->res_clean && c->cfg.time_mode == 0 && pre_enabled;
+    const bool pre = c->pre_ok && c->res_clean && c->cfg.time_mode == 0 && c->tn.pre != 0;
     if (!pre) c->pre_ok = false;
     HIPCHK(launch_finalize_reads(v, c->ra, base, c->head, c->tail, c->tp.thr_fail, c->tp.fail_q,
                                  c->res_buf + c->res_words, c->cfg.n_channels, c->res_buf + c->res_words + 8, !pre, s));
@@ -655,9 +655,8 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     // instead of a second pass over the text (ppqc_fastq_gpu.hip).  It pays when the two end spans of a line are a small
     // part of it; the scan has to be chosen before the line count is known, so the last text's mean line length decides
     // (the first text of a context is taken to be long; a wrong guess costs the scan pass its extra arithmetic, nothing
-    // else).  PPQC_FASTQ_SUMS = 0 | 2: never / always (A/B runs and tests).
-    const char* fs_env = getenv("PPQC_FASTQ_SUMS");
-    const int fs_mode = fs_env ? atoi(fs_env) : 1;
+    // else).  Tuning::fastq_sums = 0 | 2: never / always (tests run every text both ways).
+    const int fs_mode = c->tn.fastq_sums >= 0 ? c->tn.fastq_sums : 1;
     const bool with_sums = fs_mode == 2 || (fs_mode == 1 && (c->fq_line_hint < 0 || c->fq_line_hint >= kFastqSumsMinLine));
     // Short lines (by the same hint): most chunks would overflow their notes and the line starts would come from a
     // second pass anyway, so the scan only counts (0.86 -> 0.45 ms for 2.2 GB of 500-base reads).
@@ -686,9 +685,9 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     // The headers need the line table only.  In front of the line-mode tile kernel their kernel runs on the same stream:
     // beside it on the auxiliary stream (also at the highest stream priority) its blocks trickle in between the tile
     // kernel's for the whole 0.72 ms and fastq_finalize waits 50 us for the last of them.  line_sum_kernel is short and
-    // leaves room: beside it the header kernel is hidden (1.29 -> 1.265 ms for the step).  PPQC_FASTQ_HDR_AUX = 0 | 2:
+    // leaves room: beside it the header kernel is hidden (1.29 -> 1.265 ms for the step).  Tuning::fastq_hdr_aux = 0 | 2:
     // always in front / always beside.
-    const int hdr_env = getenv("PPQC_FASTQ_HDR_AUX") ? atoi(getenv("PPQC_FASTQ_HDR_AUX")) : 1;
+    const int hdr_env = c->tn.fastq_hdr_aux >= 0 ? c->tn.fastq_hdr_aux : 1;
     const bool hdr_aux = hdr_env == 2 || (from_sums && hdr_env != 0);
     if (hdr_aux) {
         HIPCHK(hipEventRecord(c->ev_fq, s));
@@ -703,7 +702,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     } else {
         // line mode: both classifiers run over the same text, every line is a segment
         BatchView v{text, text, c->fq.line_off, n_lines, n, nullptr, shift, nullptr, nullptr, nullptr};
-        HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->dense, c->n_cu, s, true));
+        HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->dense, c->tn, s, true));
     }
     if (hdr_aux) HIPCHK(hipStreamWaitEvent(s, c->ev_hdr, 0));
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
@@ -1249,6 +1248,24 @@ int ppqc_compat_dist_count(ppqc_ctx* c, void** counts, uint64_t* n) {
     *counts = c->cc;
     *n = c->cfg.n_channels;
     return mark_busy(c);
+}
+
+int ppqc_set_tuning(ppqc_ctx* c, const char* name, int value) {
+    if (!c || !name) return fail(PPQC_E_INVALID, "null argument");
+    struct { const char* n; int* p; int lo, hi; } knobs[] = {
+        {"tile_dense", &c->tn.tile_dense, -1, 1},       {"dense_len", &c->tn.dense_len, -1, 1 << 16},
+        {"tile_all", &c->tn.tile_all, -1, 1},           {"tile_shift", &c->tn.tile_shift, -1, kMaxTileShift},
+        {"pre", &c->tn.pre, -1, 1},                     {"fastq_sums", &c->tn.fastq_sums, -1, 2},
+        {"fastq_hdr_aux", &c->tn.fastq_hdr_aux, -1, 2},
+    };
+    for (auto& k : knobs)
+        if (strcmp(name, k.n) == 0) {
+            if (value < k.lo || value > k.hi || (k.p == &c->tn.tile_shift && value >= 0 && value < kMinTileShift))
+                return fail(PPQC_E_INVALID, std::string("ppqc_set_tuning: value out of range for ") + name);
+            *k.p = value;
+            return PPQC_OK;
+        }
+    return fail(PPQC_E_INVALID, std::string("ppqc_set_tuning: unknown knob ") + name);
 }
 
 int ppqc_bind_thread(ppqc_ctx* c) {

@@ -84,8 +84,19 @@ struct DenseList {
     int parity;
 };
 uint64_t dense_list_words(uint64_t n_tiles);
+// ppqc_set_tuning: which of several code paths that give the same results a context takes (-1 = the library's own
+// choice).  Tests hold the paths to each other, tools/tile_ab.py times them; nothing in the library reads the environment.
+struct Tuning {
+    int tile_dense = -1;    // 0: every tile stays in tile_kernel; 1: every tile goes onto the dense list; -1: per-tile probe
+    int dense_len = -1;     // a tile is dense when its reads average fewer bytes than this (kDenseLen)
+    int tile_all = -1;      // 1: dense_kernel alone over every tile; 0: always the pair; -1: by the batch's mean read length
+    int tile_shift = -1;    // log2 of the tile size (12 .. 16); -1: by the batch's size
+    int pre = -1;           // 0: no index kernel at submit time (extremes at finalize time); -1 / 1: whenever possible
+    int fastq_sums = -1;    // FASTQ text: 0 line-mode second pass, 2 span sums of the scan pass, -1 / 1 by the last text's lines
+    int fastq_hdr_aux = -1; // FASTQ text: 0 header kernel in front of the line pass, 2 beside it, -1 / 1 beside line_sum only
+};
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
-                              Partial* head, Partial* tail, DenseList& dl, int n_cu, hipStream_t s,
+                              Partial* head, Partial* tail, DenseList& dl, const Tuning& tn, hipStream_t s,
                               bool line_mode = false);
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint64_t thr_fail, double fail_q, uint64_t* csr_errors,

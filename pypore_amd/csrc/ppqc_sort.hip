@@ -7,8 +7,6 @@
 //   hist    : per-wave 256-bin digit histogram in LDS            -> counts[digit][wave]
 //   scan    : one block per digit scans its row, then the scatter waves prefix the 256 digit totals themselves
 //   scatter : per 64 keys, ballot-based match-any gives each lane its rank among equal digits (wave64: 64-bit masks)
-#include <stdlib.h>
-
 #include "ppqc_internal.hpp"
 
 namespace ppqc {
@@ -18,8 +16,7 @@ constexpr int kSortUnroll = 8;
 
 static inline void sort_geometry(uint64_t n, uint32_t* nw, uint32_t* chunk) {
     uint64_t c = (n + kMaxSortWaves - 1) / kMaxSortWaves;
-    uint64_t cmin = 512;   // measured on MI355X, 10^6 keys: whole step 3.51 ms with 2048, 3.47 with 1024, 3.42 with 512
-    if (const char* e = getenv("PPQC_SORT_MIN_CHUNK")) cmin = (uint64_t)atoi(e) >= 64 ? (uint64_t)atoi(e) : cmin;   // A/B knob
+    const uint64_t cmin = 512;   // measured on MI355X, 10^6 keys: whole step 3.51 ms with 2048, 3.47 with 1024, 3.42 with 512
     if (c < cmin) c = cmin;
     c = (c + 63) & ~63ull;
     *chunk = (uint32_t)c;

@@ -4,8 +4,6 @@
 // Replaces the aggregation of parsing_func (lib/fast5_reader.py:117-145 == lib/multi_read_fast5_reader.py:47-77), the
 // sums of FastStats (lib/seq_routines.py:99-137) and the per-channel tables of result_plotting / ChannelPlotter_f
 // (:378-394, :507-514, :673-680).  All cells are u64 so one RCCL dtype covers the merged buffer.
-#include <stdlib.h>
-
 #include "ppqc_internal.hpp"
 
 namespace ppqc {
@@ -413,12 +411,6 @@ hipError_t launch_init_results(uint64_t* res, uint64_t n_sum, uint64_t nch1, boo
     return hipGetLastError();
 }
 
-static inline unsigned env_or(const char* name, unsigned dflt) {
-    const char* e = getenv(name);
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? (unsigned)v : dflt;
-}
-
 static inline unsigned grid_for(uint64_t n, unsigned cap) {
     uint64_t b = (n + 255) / 256;
     if (b < 1) b = 1;
@@ -433,8 +425,8 @@ hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uin
     if (n == 0) return hipSuccess;
     // a length of 2^32-1 cannot be told from "unseen" in the u32 LDS copy: lengths are < 2^32-1 by the API contract
     const uint32_t nchL = tp.lay.n_channels <= kExtremesLdsChannels ? tp.lay.n_channels : 0;
-    hipLaunchKernelGGL(extremes_kernel<false>, dim3(grid_for(n, env_or("PPQC_EXT_BLOCKS", 256))),
-                       dim3(env_or("PPQC_EXT_THREADS", 512)), (size_t)nchL * 8, s, BatchView{}, (uint64_t)0, ra, n, tp,
+    hipLaunchKernelGGL(extremes_kernel<false>, dim3(grid_for(n, 256)),
+                       dim3(512), (size_t)nchL * 8, s, BatchView{}, (uint64_t)0, ra, n, tp,
                        max_buf, min_buf, tminmax, nchL, write_lens ? 1 : 0, (uint64_t*)nullptr, (uint64_t*)nullptr);
     return hipGetLastError();
 }
@@ -449,8 +441,8 @@ hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays r
     // beside it displaces one of its waves for as long as it lives, and under a saturated HBM a latency-bound wave lives
     // long.  64 x 256 threads finish well inside the tile kernel of any batch worth the trouble and cost it next to
     // nothing (2048 waves of 8 reads each cost config 2 about 15 us of tile-kernel time).
-    hipLaunchKernelGGL(extremes_kernel<true>, dim3(grid_for(b.n_reads, env_or("PPQC_PRE_BLOCKS", 64))),
-                       dim3(env_or("PPQC_PRE_THREADS", 256)), (size_t)nchL * 8, s, b, base, ra, b.n_reads, tp, max_buf,
+    hipLaunchKernelGGL(extremes_kernel<true>, dim3(grid_for(b.n_reads, 64)),
+                       dim3(256), (size_t)nchL * 8, s, b, base, ra, b.n_reads, tp, max_buf,
                        min_buf, tminmax, nchL, 1, bound, bound_host);
     return hipGetLastError();
 }
@@ -478,9 +470,9 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
     const size_t lds = lds_for(nchL);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     // few, fat blocks: every block flushes its private tables once (measured on MI355X, config 2: 256 x 512 threads
-    // 0.317 ms for the whole finalize, 512 x 256: 0.34, 2048 x 256: 0.42; PPQC_TAB_* / PPQC_EXT_* are A/B knobs)
-    hipLaunchKernelGGL(tables_kernel, dim3(grid_for(n, env_or("PPQC_TAB_BLOCKS", 256))),
-                       dim3(env_or("PPQC_TAB_THREADS", 512)), lds, s, ra, n, tp, sum_buf, max_buf, nchL);
+    // 0.317 ms for the whole finalize, 512 x 256: 0.34, 2048 x 256: 0.42)
+    hipLaunchKernelGGL(tables_kernel, dim3(grid_for(n, 256)),
+                       dim3(512), lds, s, ra, n, tp, sum_buf, max_buf, nchL);
     const uint64_t cells = (uint64_t)tp.lay.n_channels * tp.lay.n_mux * tp.lay.n_time_bins;
     hipLaunchKernelGGL(cmh_unpack_kernel, dim3(grid_for(cells, 512)), dim3(256), 0, s, sum_buf, tp.lay, n, max_buf);
     if (tp.compat_flags & PPQC_COMPAT_MULTI_READ_SINGLE)

@@ -10,20 +10,18 @@
 // wave-uniform scalars walked along the offsets array.  A span that lies inside one read takes the fast path (SWAR byte
 // classification, v_sad_u8 byte sums, a 256-entry fixed-point LUT in LDS for 10^(-q/10)).  A read boundary cuts exactly
 // one lane's vectors: the other lanes add their fast-path sums under a lane mask and the cut lane's 32 bytes are
-// classified one byte per lane (boundaries_bytepar); batches of very short reads take a second instantiation that
-// handles all boundaries of a span in one pass (boundary_rounds).  All quantities are integers, so every
+// classified one byte per lane (boundaries_bytepar); tiles in which many reads end are left to dense_kernel, which
+// works in entry space (below).  All quantities are integers, so every
 // decomposition gives the same sums.  Ultra-long reads are
 // thereby split over as many wavefronts as they have tiles; each wave writes a head/tail partial per tile and
 // finalize_reads merges them in tile order.  Everything is integer, so results do not depend on the decomposition.
-#include <stdlib.h>
-
 #include "ppqc_internal.hpp"
 
 namespace ppqc {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// Sums over the first x (0..16) bytes of the lane's vectors (VECB kernels): the bytes from x on are zeroed (a zero byte
+// Sums over the first x (0..16) bytes of the lane's vectors (dense_kernel): the bytes from x on are zeroed (a zero byte
 // matches no base class and adds nothing to the byte sum) and their LUT entries, lut[0] = 2^52 each, are taken off again.
 __device__ __noinline__ Acc vec_prefix(uint4 vb, uint4 vq, int x, const uint64_t* lut) {
     uint32_t m[4];
@@ -115,7 +113,7 @@ struct TileCtx {
     const uint64_t* lut;
     int lane;
     uint32_t lane_off;
-    uint32_t* xs;   // 64 words of LDS per wave (boundary_rounds)
+    uint32_t* xs;   // 64 words of LDS per wave (cut_lane_bytes, span_scan)
     bool line;      // line mode (FASTQ text): the sums of header and '+' lines (even line numbers) are never read
 };
 
@@ -247,94 +245,12 @@ __device__ __forceinline__ void boundaries_bytepar(const uint4& vb, const uint4&
     }
 }
 
-// A span that contains read boundaries, all of them at once.  Lane i of the offsets window owns the read that ends at
-// win_i; lane v of the data owns 16 bytes.  With E = exclusive wave scan of the per-lane sums and pre_v = sums over the
-// first x bytes of lane v (x = where a boundary cuts lane v's vector; ONE masked pass serves every boundary of the
-// span), the sums from the span start to boundary i are P_i = E[vl_i] + pre[vl_i], and the read owns P_i - P_(i-1).
-// The first read also owns what earlier spans left in acc (one wave reduction per span, not per read); the others
-// started inside this span and are stored by their own lanes.  Returns false when two different cuts fall into one
-// 16-byte vector (reads shorter than 16 bytes): the sequential loop finishes the span from the state left here.
-__device__ __forceinline__ bool boundary_rounds(const uint4& vb, const uint4& vq, const Acc& tot, uint64_t span_start,
-                                                uint64_t span_end, Walk& w, Acc& acc, Acc& prev, const TileCtx& c) {
-    const int lane = c.lane;
-    const uint64_t tc = pack_cnt(tot.gcs, tot.n, tot.qb), te = tot.err;   // span level: err <= 1 KiB * 2^52 fits u64
-    uint64_t ic = tc, ie = te;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint64_t uc = __shfl_up(ic, o), ue = __shfl_up(ie, o);
-        if (lane >= o) { ic += uc; ie += ue; }
-    }
-    const uint64_t Ec = ic - tc, Ee = ie - te;
-    uint64_t baseC = 0, baseE = 0;   // P of the last boundary of the previous round
-    bool first = true, ok = true;
-    for (;;) {
-        int pos = (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w.r - w.win_r0));
-        if (!w.win_ok || w.r < w.win_r0 || w.r - w.win_r0 >= 64) {
-            uint64_t idx = w.r + 1 + (uint64_t)lane;
-            idx = idx < c.R ? idx : c.R;
-            w.win = c.off[idx];
-            w.win_r0 = w.r;
-            w.win_ok = true;
-            pos = 0;
-        }
-        const bool isb = lane >= pos && w.win_r0 + (uint64_t)lane < c.R && w.win < span_end;
-        const uint64_t nbm = __ballot(isb);
-        if (!nbm) break;
-        const uint32_t rel = isb ? (uint32_t)(w.win - span_start) : 0u;
-        const int vl = (int)(rel >> 4), x = (int)(rel & 15u);
-        const int vlp = __shfl_up(vl, 1), xp = __shfl_up(x, 1);
-        if (__ballot(isb && lane > pos && vlp == vl && xp != x)) { ok = false; break; }
-        // tell every data lane where its vector is cut (0 = not cut)
-        c.xs[lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-        if (isb) c.xs[vl] = (uint32_t)x;
-        __builtin_amdgcn_wave_barrier();
-        const int myx = (int)c.xs[lane];
-        __builtin_amdgcn_wave_barrier();
-        Acc pre{0, 0, 0, 0};
-        if (__ballot(myx != 0)) pre = vec_prefix(vb, vq, myx, c.lut);
-        const uint64_t Qc = Ec + pack_cnt(pre.gcs, pre.n, pre.qb), Qe = Ee + pre.err;
-        const uint64_t Pc = __shfl(Qc, vl), Pe = __shfl(Qe, vl);
-        uint64_t pc = __shfl_up(Pc, 1), pe = __shfl_up(Pe, 1);
-        if (lane == pos) { pc = baseC; pe = baseE; }
-        const uint64_t sc = Pc - pc, se = Pe - pe;   // cumulative, so no field of the packed counters borrows
-        if (first) {
-            const uint64_t fc = readlane_u64(sc, pos), fe = readlane_u64(se, pos);
-            if (lane == 0) { acc.gcs += cnt_gcs(fc); acc.n += cnt_n(fc); acc.qb += cnt_qb(fc); acc.err += fe; }
-            flush_read(acc, w, c);
-        }
-        if (isb && !(first && lane == pos)) {
-            const uint64_t ri = c.read_base + w.win_r0 + (uint64_t)lane;
-            c.ra.rec_cnt[ri] = sc;
-            c.ra.rec_hi[ri] = se >> 32;
-            c.ra.rec_lo[ri] = se & 0xffffffffull;
-        }
-        const int hb = 63 - __clzll((long long)nbm);
-        baseC = readlane_u64(Pc, hb);
-        baseE = readlane_u64(Pe, hb);
-        const int lvl = __builtin_amdgcn_readlane(vl, hb);
-        prev = lane < lvl ? tot : (lane == lvl ? pre : Acc{0, 0, 0, 0});
-        w.rs = readlane_u64(w.win, hb);
-        w.r = w.win_r0 + (uint64_t)hb + 1;
-        first = false;
-        if (hb != 63 || w.r >= c.R) break;   // else the window is used up and more reads may end in this span
-    }
-    w.done = w.r >= c.R;
-    if (!w.done) {
-        const uint64_t d = w.r - w.win_r0;
-        w.re = (w.win_ok && w.r >= w.win_r0 && d < 64) ? readlane_u64(w.win, (int)d) : uniform_u64(c.off[w.r + 1]);
-        w.re_rel = rel_end(w.re, c.tile_start);
-    }
-    return ok;
-}
-
-// One 1 KiB span (both streams) of the tile: fast path if it lies inside the current read, else the vectorised
-// boundary pass above (or, for reads shorter than a vector, one prefix-masked pass per boundary).
-template <bool LINE, bool VECB>
+// One 1 KiB span (both streams) of the tile: fast path if it lies inside the current read, else the boundaries one
+// after the other (boundaries_bytepar).
+template <bool LINE>
 __device__ __forceinline__ void process_span(const uint4& vb, const uint4& vq, uint32_t sp, Walk& w, Acc& acc,
                                              const TileCtx& c) {
     const uint32_t span_rel = sp * kSpan;
-    const uint64_t span_end = c.tile_start + span_rel + kSpan;   // end of the FULL span
     const uint32_t span_end_rel = span_rel + kSpan;
     Acc tot;
     if (LINE && w.re_rel >= span_end_rel) {
@@ -351,35 +267,15 @@ __device__ __forceinline__ void process_span(const uint4& vb, const uint4& vq, u
         acc_add(acc, tot);
         if (w.re_rel == span_end_rel) {
             flush_read(acc, w, c);
-            walk_advance<VECB, !VECB>(w, c);
+            walk_advance<false, true>(w, c);
         }
-    } else if (!VECB) {
-        boundaries_bytepar(vb, vq, tot, span_rel, w, acc, c);
     } else {
-        // one or more reads end strictly inside this span (or the data ends inside it)
-        Acc prev{0, 0, 0, 0};
-        const int vrel = (int)(span_rel + c.lane_off);
-        const bool finished = boundary_rounds(vb, vq, tot, c.tile_start + span_rel, span_end, w, acc, prev, c);
-        if (!finished && !w.done && w.re < span_end) do {
-            int x = (int)(uint32_t)(w.re - c.tile_start) - vrel;
-            x = x < 0 ? 0 : (x > kVec ? kVec : x);
-            const Acc f = vec_prefix(vb, vq, x, c.lut);
-            acc_add(acc, acc_sub(f, prev));
-            prev = f;
-            flush_read(acc, w, c);
-            walk_advance<VECB>(w, c);
-        } while (!w.done && w.re < span_end);
-        if (!w.done) {
-            acc = acc_sub(tot, prev);   // the read that starts in this span owns the rest of it
-            if (w.re == span_end) {
-                flush_read(acc, w, c);   // starts and ends in this tile
-                walk_advance<VECB>(w, c);
-            }
-        }
+        boundaries_bytepar(vb, vq, tot, span_rel, w, acc, c);
     }
 }
 
-template <int NB, bool NT, bool LINE>
+// The streams are read once: nontemporal loads (measured +16 % on MI355X against temporal ones).
+template <int NB, bool LINE>
 __device__ __forceinline__ void load_batch(uint4 (&vb)[NB], uint4 (&vq)[NB], const uint8_t* __restrict__ pb,
                                            const uint8_t* __restrict__ pq, uint32_t s0, uint32_t lane_off,
                                            uint32_t last_vec) {
@@ -387,33 +283,9 @@ __device__ __forceinline__ void load_batch(uint4 (&vb)[NB], uint4 (&vq)[NB], con
     for (int i = 0; i < NB; ++i) {
         uint32_t o = (s0 + i) * kSpan + lane_off;
         o = o < last_vec ? o : last_vec;   // clamp instead of predicating: out-of-range lanes are masked by the walk
-        if (LINE) {   // one stream: the text is both
-            const u32x4 tb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pb + o));
-            vb[i] = make_uint4(tb[0], tb[1], tb[2], tb[3]);
-        } else if (NT) {   // read-once streams: nontemporal loads (measured +16 % on MI355X)
-            const u32x4 tb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pb + o));
-            const u32x4 tq = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pq + o));
-            vb[i] = make_uint4(tb[0], tb[1], tb[2], tb[3]);
-            vq[i] = make_uint4(tq[0], tq[1], tq[2], tq[3]);
-        } else {
-            vb[i] = *reinterpret_cast<const uint4*>(pb + o);
-            vq[i] = *reinterpret_cast<const uint4*>(pq + o);
-        }
-    }
-}
-
-// spans [I0, I1) of the batch that starts at span s0
-template <int I0, int I1, int NB, bool NT, bool LINE>
-__device__ __forceinline__ void load_part(uint4 (&vb)[NB], uint4 (&vq)[NB], const uint8_t* __restrict__ pb,
-                                          const uint8_t* __restrict__ pq, uint32_t s0, uint32_t lane_off,
-                                          uint32_t last_vec) {
-#pragma unroll
-    for (int i = I0; i < I1; ++i) {
-        uint32_t o = (s0 + i) * kSpan + lane_off;
-        o = o < last_vec ? o : last_vec;
         const u32x4 tb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pb + o));
         vb[i] = make_uint4(tb[0], tb[1], tb[2], tb[3]);
-        if (!LINE) {
+        if (!LINE) {   // line mode has one stream: the text is both
             const u32x4 tq = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pq + o));
             vq[i] = make_uint4(tq[0], tq[1], tq[2], tq[3]);
         }
@@ -422,10 +294,10 @@ __device__ __forceinline__ void load_part(uint4 (&vb)[NB], uint4 (&vq)[NB], cons
 
 constexpr int kLineGroup = 4;
 
-template <int NB, bool LINE, bool VECB>
+template <int NB, bool LINE>
 __device__ __forceinline__ void process_batch(const uint4 (&vb)[NB], const uint4 (&vq)[NB], uint32_t s0,
                                               uint32_t n_spans, Walk& w, Acc& acc, const TileCtx& c) {
-    if (LINE && !VECB && NB % kLineGroup == 0) {
+    if (LINE && NB % kLineGroup == 0) {
         // Line mode: kLineGroup spans at once when the current line covers all of them -- straight-line code whose LUT
         // reads and sums the compiler interleaves across the spans, and one set of scalar tests instead of four
 #pragma unroll
@@ -449,7 +321,7 @@ __device__ __forceinline__ void process_batch(const uint4 (&vb)[NB], const uint4
 #pragma unroll
                 for (int k = 0; k < kLineGroup; ++k) {
                     if (s0 + g + k >= n_spans || w.done) break;
-                    process_span<LINE, VECB>(vb[g + k], vb[g + k], s0 + g + k, w, acc, c);
+                    process_span<LINE>(vb[g + k], vb[g + k], s0 + g + k, w, acc, c);
                 }
             }
         }
@@ -458,11 +330,10 @@ __device__ __forceinline__ void process_batch(const uint4 (&vb)[NB], const uint4
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         if (s0 + i >= n_spans || w.done) break;
-        process_span<LINE, VECB>(vb[i], LINE ? vb[i] : vq[i], s0 + i, w, acc, c);
+        process_span<LINE>(vb[i], LINE ? vb[i] : vq[i], s0 + i, w, acc, c);
     }
 }
 
-// NB spans per batch; NT nontemporal loads; PIPE: two register sets, the next batch is in flight while one is processed.
 // What tile_kernel needs to hand dense tiles over to dense_kernel (see "the boundary strategy is chosen per tile" below).
 // The dense list.  64 sub-lists, each with a counter of its own (one hot counter took 380 us for 30 000 appends): a
 // tile goes to sub-list (tile / 4) % 64, which holds at most dense_sub_cap(n_tiles) entries.  Layout in u64 words:
@@ -482,7 +353,8 @@ __host__ __device__ inline DenseOut make_dense_out(const uint64_t* base, int par
            ((uint64_t)(T & 8191u) << 51);
 }
 
-template <int NB, bool NT, bool PIPE, bool LINE, bool VECB, int WPB = 4>
+// NB spans per batch (all of their loads in flight before the first wait), WPB waves per block.
+template <int NB, bool LINE, int WPB = 4>
 __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __restrict__ lut_g, const ReadArrays& ra,
                                           uint64_t read_base, Partial* __restrict__ head, Partial* __restrict__ tail,
                                           uint64_t n_tiles, const DenseOut dz = make_dense_out(nullptr, 0, 1, 64)) {
@@ -511,7 +383,7 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
         c.t = t; c.tile_start = tile_start;
 
         uint4 vb[NB], vq[NB];
-        load_batch<NB, NT, LINE>(vb, vq, pb, pq, 0, c.lane_off, last_vec);   // in flight during the read search
+        load_batch<NB, LINE>(vb, vq, pb, pq, 0, c.lane_off, last_vec);   // in flight during the read search
 
         Walk w;
         w.r = find_read(c.off, c.R, tile_start, lane);
@@ -519,7 +391,7 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
         // requested in front of them and looked at behind them, so it adds no latency of its own
         const uint32_t dmode = (uint32_t)(dz >> 49) & 3u;
         uint64_t probe = ~0ull;
-        if (!VECB && dmode == 0) {
+        if (dmode == 0) {
             const uint64_t T = dz >> 51;   // >= 1
             // (fewer than T reads left: not dense -- one stray dense tile, the batch's last, would cost dense_kernel a
             // whole tile's latency, 40 us, behind this kernel)
@@ -528,8 +400,8 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
         w.rs = uniform_u64(c.off[w.r]);
         w.done = false;
         w.win = 0; w.win_r0 = 0; w.win_ok = false;
-        w.re = VECB ? read_end(w, c, w.r) : uniform_u64(c.off[w.r + 1]);
-        if (!VECB && dmode != 1 && (dmode == 2 || probe <= tile_start + tile_valid)) {   // left to dense_kernel
+        w.re = uniform_u64(c.off[w.r + 1]);
+        if (dmode != 1 && (dmode == 2 || probe <= tile_start + tile_valid)) {   // left to dense_kernel
             if (lane == 0) {
                 uint64_t* base = (uint64_t*)(uintptr_t)(dz & 0xFFFFFFFFFFFFull);
                 const uint64_t j = (t >> 2) & (kDenseSubs - 1), cap = dense_sub_cap(n_tiles);
@@ -540,23 +412,12 @@ __device__ __forceinline__ void tile_body(const BatchView& b, const uint64_t* __
             continue;
         }
         w.re_rel = rel_end(w.re, tile_start);
-        w.re2 = 0;
-        if (!VECB) w.re2 = sload_u64(c.off, w.r + 2 < c.R ? w.r + 2 : c.R);
+        w.re2 = sload_u64(c.off, w.r + 2 < c.R ? w.r + 2 : c.R);
         Acc acc{0, 0, 0, 0};
 
-        if (PIPE) {
-            uint4 ub[NB], uq[NB];
-            for (uint32_t s0 = 0; s0 < n_spans && !w.done; s0 += 2 * NB) {
-                if (s0 + NB < n_spans) load_batch<NB, NT, LINE>(ub, uq, pb, pq, s0 + NB, c.lane_off, last_vec);
-                process_batch<NB, LINE, VECB>(vb, vq, s0, n_spans, w, acc, c);
-                if (s0 + 2 * NB < n_spans) load_batch<NB, NT, LINE>(vb, vq, pb, pq, s0 + 2 * NB, c.lane_off, last_vec);
-                if (s0 + NB < n_spans) process_batch<NB, LINE, VECB>(ub, uq, s0 + NB, n_spans, w, acc, c);
-            }
-        } else {
-            for (uint32_t s0 = 0; s0 < n_spans && !w.done; s0 += NB) {
-                if (s0) load_batch<NB, NT, LINE>(vb, vq, pb, pq, s0, c.lane_off, last_vec);
-                process_batch<NB, LINE, VECB>(vb, vq, s0, n_spans, w, acc, c);
-            }
+        for (uint32_t s0 = 0; s0 < n_spans && !w.done; s0 += NB) {
+            if (s0) load_batch<NB, LINE>(vb, vq, pb, pq, s0, c.lane_off, last_vec);
+            process_batch<NB, LINE>(vb, vq, s0, n_spans, w, acc, c);
         }
         // a read that continues into the next tile leaves a partial: tail if it started here, else head
         if (!w.done && w.rs < tile_start + kTile && w.re > tile_start + kTile && !(LINE && !(w.r & 1))) {
@@ -902,7 +763,7 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
         const uint8_t* __restrict__ pq = b.quals + tile_start;
         c.t = t; c.tile_start = tile_start;
         uint4 vb[ND], vq[ND];
-        load_part<0, ND, ND, true, LINE>(vb, vq, pb, pq, 0, c.lane_off, last_vec);
+        load_batch<ND, LINE>(vb, vq, pb, pq, 0, c.lane_off, last_vec);
         Walk w;
         w.r = ALL ? find_read(c.off, c.R, tile_start, lane) : e >> 32;
         w.rs = uniform_u64(c.off[w.r]);
@@ -961,7 +822,7 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
         };
 
         for (uint32_t s0 = 0; s0 < n_spans && !w.done; s0 += ND) {
-            if (s0) load_part<0, ND, ND, true, LINE>(vb, vq, pb, pq, s0, c.lane_off, last_vec);
+            if (s0) load_batch<ND, LINE>(vb, vq, pb, pq, s0, c.lane_off, last_vec);
 #pragma unroll
             for (int k = 0; k < ND; ++k) {
                 if (s0 + k >= n_spans || w.done) break;
@@ -1100,31 +961,20 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
     }
 }
 
-// VECB: read boundaries of a span handled all at once (boundary_rounds) instead of one after the other.  It needs 158
-// VGPRs (3 instead of 4 waves per SIMD) and its fast path is slower, so it is a separate instantiation that the
-// launcher picks for batches of very short reads (mean below kVecbMeanLen bytes), where several reads end in most spans.
-template <int NB, bool NT, bool PIPE, bool VECB>
-__global__ __launch_bounds__(256, (VECB ? 3 : 4)) void tile_kernel(BatchView b, const uint64_t* __restrict__ lut_g,
-                                                                  ReadArrays ra, uint64_t read_base,
-                                                                  Partial* __restrict__ head, Partial* __restrict__ tail,
-                                                                  uint64_t n_tiles, DenseOut dz) {
-    tile_body<NB, NT, PIPE, false, VECB>(b, lut_g, ra, read_base, head, tail, n_tiles, dz);
+// The two-stream kernel: 8 spans of both streams per batch (16 loads, 16 KiB in flight per wave), 4 waves per SIMD at
+// exactly 128 VGPRs.
+__global__ __launch_bounds__(256, 4) void tile_kernel(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra,
+                                                      uint64_t read_base, Partial* __restrict__ head,
+                                                      Partial* __restrict__ tail, uint64_t n_tiles, DenseOut dz) {
+    tile_body<8, false>(b, lut_g, ra, read_base, head, tail, n_tiles, dz);
 }
 
-// Line mode (FASTQ text): one stream.  This instantiation serves PPQC_LINE_VECB (all boundaries of a span at once).
-template <int NB, bool VECB>
-__global__ __launch_bounds__(256, (VECB ? 4 : 5))
-void tile_kernel_line(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra, uint64_t read_base,
-                      Partial* __restrict__ head, Partial* __restrict__ tail, uint64_t n_tiles, DenseOut dz) {
-    tile_body<NB, true, false, true, VECB>(b, lut_g, ra, read_base, head, tail, n_tiles, dz);
-}
-
-// The default line kernel: WPB waves per block, OCC waves per SIMD (launch_tile_kernel says which and why).
+// Line mode (FASTQ text, one stream): WPB waves per block, OCC waves per SIMD (launch_tile_kernel says which and why).
 template <int NB, int WPB, int OCC>
 __global__ __launch_bounds__(64 * WPB, OCC)
 void tile_kernel_line_w(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra, uint64_t read_base,
                         Partial* __restrict__ head, Partial* __restrict__ tail, uint64_t n_tiles, DenseOut dz) {
-    tile_body<NB, true, false, true, false, WPB>(b, lut_g, ra, read_base, head, tail, n_tiles, dz);
+    tile_body<NB, true, WPB>(b, lut_g, ra, read_base, head, tail, n_tiles, dz);
 }
 
 // One thread per read: merge the partials of reads that span tiles, define empty reads, then decode the raw sums.
@@ -1205,57 +1055,27 @@ constexpr uint32_t kDenseLen = 768;    // a tile is dense when its reads average
 constexpr uint32_t kDenseAllLen = 1792, kDenseAllLenSmall = 2560;
 constexpr uint64_t kSmallBatchBytes = 256ull << 20;
 
-template <int NB, bool NT, bool PIPE, bool LINE = false, bool VECB = false>
-static hipError_t launch_tile_variant(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
-                                      Partial* head, Partial* tail, int n_cu, int blocks_per_cu, const DenseOut& dz,
-                                      hipStream_t s) {
-    const uint64_t n_tiles = (b.n_bytes + (1ull << b.tile_shift) - 1) >> b.tile_shift;
-    // Default: one tile per wavefront, 4 waves per block.  The hardware dispatcher then acts as the dynamic tile
-    // scheduler; measured on MI355X (config 2) this beats every persistent grid: 3.07 ms vs 3.13 (64 blocks/CU),
-    // 3.37 (8/CU), 3.6 (resident blocks only).
-    uint64_t blocks = (n_tiles + 3) / 4;
-    if (blocks_per_cu > 0) {   // tuning knob: persistent grid of blocks_per_cu blocks per CU, grid-stride over tiles
-        const uint64_t cap = (uint64_t)n_cu * blocks_per_cu;
-        if (blocks > cap) blocks = cap;
-    }
-    if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
-    if (LINE)
-        hipLaunchKernelGGL((tile_kernel_line<NB, VECB>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base,
-                           head, tail, n_tiles, dz);
-    else
-        hipLaunchKernelGGL((tile_kernel<NB, NT, PIPE, VECB>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra,
-                           read_base, head, tail, n_tiles, dz);
-    return hipGetLastError();
-}
-
-// The per-read kernels of one batch: tile_kernel over every tile, then dense_kernel over the tiles it left on the list.
-// Knobs for A/B measurements (tools/tile_ab.py): PPQC_TILE_DENSE = 0 | 1 makes no / every tile dense,
-// PPQC_TILE_DENSE_LEN moves the threshold, PPQC_TILE_VARIANT = 3 | 2 | 108 run one of the older single-kernel
-// instantiations (nontemporal / temporal loads / all boundaries of a span at once with a per-lane window) on every tile,
-// PPQC_TILE_BLOCKS_PER_CU a persistent grid.
+// The per-read kernels of one batch: tile_kernel over every tile (one tile per wavefront, 4 waves per block: the
+// hardware dispatcher is the dynamic tile scheduler; on config 2 that beat every persistent grid, 3.07 ms against 3.13
+// with 64 blocks per CU, 3.37 with 8, 3.6 with resident blocks only), then dense_kernel over the tiles it left on the
+// list -- or, for a batch that is dense on average, dense_kernel alone over every tile.  `tn` (ppqc_set_tuning) can
+// force either kernel on every tile and move the thresholds: the results are the same, the tests hold them to each other.
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
-                              Partial* head, Partial* tail, DenseList& dl, int n_cu, hipStream_t s, bool line_mode) {
+                              Partial* head, Partial* tail, DenseList& dl, const Tuning& tn, hipStream_t s,
+                              bool line_mode) {
     if (b.n_bytes == 0 || b.n_reads == 0) return hipSuccess;
-    const char* v = getenv("PPQC_TILE_VARIANT");
-    const char* bp = getenv("PPQC_TILE_BLOCKS_PER_CU");
-    const char* dm = getenv("PPQC_TILE_DENSE");
-    const char* dlen = getenv("PPQC_TILE_DENSE_LEN");
-    const int bpc = bp ? atoi(bp) : 0;
-    const int variant = v ? atoi(v) : 0;
-    uint32_t mode = dm ? (atoi(dm) ? 2u : 1u) : 0u;
-    if (!dl.base || variant != 0) mode = 1;
-    uint32_t dense_len = dlen ? (uint32_t)atoi(dlen) : kDenseLen;
+    uint32_t mode = tn.tile_dense < 0 ? 0u : (tn.tile_dense ? 2u : 1u);   // 0 probe every tile, 1 none dense, 2 all dense
+    if (!dl.base) mode = 1;
+    uint32_t dense_len = tn.dense_len > 0 ? (uint32_t)tn.dense_len : kDenseLen;
     if (dense_len < 16) dense_len = 16;
     uint32_t T = (uint32_t)((1ull << b.tile_shift) / dense_len);
     T = T < 1 ? 1 : (T > 8191 ? 8191 : T);
-    DenseOut dz = make_dense_out(dl.base, dl.parity, mode, T);
-    hipError_t e;
-    // a batch that is dense on average: dense_kernel alone, over every tile (PPQC_TILE_ALL = 0 | 1 overrides the choice)
-    const char* da = getenv("PPQC_TILE_ALL");
-    const bool all = da ? atoi(da) != 0
-                        : (mode == 0 && b.n_bytes / b.n_reads < (b.n_bytes < kSmallBatchBytes ? kDenseAllLenSmall : kDenseAllLen));
-    if (all && variant == 0 && !(line_mode && getenv("PPQC_LINE_VECB") && atoi(getenv("PPQC_LINE_VECB")) != 0)) {
-        const uint64_t n_tiles = (b.n_bytes + (1ull << b.tile_shift) - 1) >> b.tile_shift;
+    const DenseOut dz = make_dense_out(dl.base, dl.parity, mode, T);
+    const uint64_t n_tiles = (b.n_bytes + (1ull << b.tile_shift) - 1) >> b.tile_shift;
+    const bool all = tn.tile_all >= 0
+                         ? tn.tile_all != 0
+                         : (mode == 0 && b.n_bytes / b.n_reads < (b.n_bytes < kSmallBatchBytes ? kDenseAllLenSmall : kDenseAllLen));
+    if (all) {
         uint64_t blocks = (n_tiles + 3) / 4;
         if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
         if (line_mode)
@@ -1267,36 +1087,26 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
         return hipGetLastError();
     }
     if (line_mode) {
-        const char* lv = getenv("PPQC_LINE_VECB");
-        if (lv && atoi(lv) != 0) {
-            mode = 1;
-            dz = make_dense_out(dl.base, dl.parity, mode, T);
-            e = launch_tile_variant<8, true, false, true, true>(b, lut_dev, ra, read_base, head, tail, n_cu, 0, dz, s);
-        } else {
-            // 4 spans per batch, taken as one group when the line covers them (process_batch), 79 VGPRs = 6 waves per
-            // SIMD, 2 waves per block: 0.70 ms for 3.97 GB of text (5.6 TB/s) against 0.76 for 8 spans, span by span,
-            // at 5 waves.  Tried on the same text, whole path: 1, 2 or 4 waves per block 2.14 / 2.15 / 2.11 TB/s;
-            // two register sets of 8 or 4 spans (the next batch in flight while one is processed) 2.07 / 2.12; groups
-            // of 4 with 8 spans per batch spill at 5 waves (1.85) and give 2.13 at 4; 12 or 16 spans per batch at 4 waves
-            // 1.95 / 1.92 (before the groups).  None of this moves the kernel by more than 2 %: what did was taking the
-            // header kernel from beside it (ppqc_fastq_gpu.hip).
-            const uint64_t n_tiles = (b.n_bytes + (1ull << b.tile_shift) - 1) >> b.tile_shift;
-            uint64_t blocks = (n_tiles + 1) / 2;
-            if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
-            hipLaunchKernelGGL((tile_kernel_line_w<kLineGroup, 2, 6>), dim3((unsigned)blocks), dim3(128), 0, s, b, lut_dev, ra,
-                               read_base, head, tail, n_tiles, dz);
-            e = hipGetLastError();
-        }
+        // 4 spans per batch, taken as one group when the line covers them (process_batch), 79 VGPRs = 6 waves per
+        // SIMD, 2 waves per block: 0.70 ms for 3.97 GB of text (5.6 TB/s) against 0.76 for 8 spans, span by span,
+        // at 5 waves.  Tried on the same text, whole path: 1, 2 or 4 waves per block 2.14 / 2.15 / 2.11 TB/s;
+        // two register sets of 8 or 4 spans (the next batch in flight while one is processed) 2.07 / 2.12; groups
+        // of 4 with 8 spans per batch spill at 5 waves (1.85) and give 2.13 at 4; 12 or 16 spans per batch at 4 waves
+        // 1.95 / 1.92 (before the groups).  None of this moves the kernel by more than 2 %: what did was taking the
+        // header kernel from beside it (ppqc_fastq_gpu.hip).
+        uint64_t blocks = (n_tiles + 1) / 2;
+        if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+        hipLaunchKernelGGL((tile_kernel_line_w<kLineGroup, 2, 6>), dim3((unsigned)blocks), dim3(128), 0, s, b, lut_dev, ra,
+                           read_base, head, tail, n_tiles, dz);
     } else {
-        switch (variant) {
-            case 2: e = launch_tile_variant<8, false, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, dz, s); break;
-            case 108: e = launch_tile_variant<8, true, false, false, true>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, dz, s); break;
-            default: e = launch_tile_variant<8, true, false>(b, lut_dev, ra, read_base, head, tail, n_cu, bpc, dz, s); break;
-        }
+        uint64_t blocks = (n_tiles + 3) / 4;
+        if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+        hipLaunchKernelGGL(tile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head, tail,
+                           n_tiles, dz);
     }
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess || mode == 1) return e;
     // dense_kernel: one tile per wave over the list; the grid covers the most entries the list can have (see there)
-    const uint64_t n_tiles = (b.n_bytes + (1ull << b.tile_shift) - 1) >> b.tile_shift;
     uint64_t bound = n_tiles;
     if (mode == 0) {
         const uint64_t most = b.n_reads / T + 1;

@@ -32,6 +32,8 @@ SUBMIT_HOOK = None   # tests: called with (kind, {name: (address, nbytes)}) for 
 
 
 class QCContext:
+    DEFAULT_TUNING = {}   # tests: knobs of ``set_tuning`` applied to every new context
+
     def __init__(self, device=0, n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=0,
                  tz_offset_s=0, ref_time_s=0, fail_q=7.0, max_reads_hint=0, compat_flags=0):
         self._lib = L.load()
@@ -45,6 +47,8 @@ class QCContext:
         self._ctx = C.c_void_p()
         L.check(self._lib.ppqc_create(C.byref(self._ctx), int(device), C.byref(cfg)))
         self.external_stream = None
+        for k, v in self.DEFAULT_TUNING.items():
+            self.set_tuning(k, v)
         self._keep = {}   # per staging slot: host arrays that must outlive the asynchronous submit
 
     # -- lifetime ---------------------------------------------------------------------------------
@@ -334,6 +338,11 @@ class QCContext:
         p, n = C.c_void_p(), C.c_uint64()
         L.check(self._lib.ppqc_compat_dist_count(self._ctx, C.byref(p), C.byref(n)))
         return DeviceArrayView(p.value, n.value, "<i8", self)
+
+    def set_tuning(self, name, value=-1):
+        """Test and measurement hook (ppqc_set_tuning): force one of several code paths that give the same results;
+        -1 gives the choice back to the library."""
+        L.check(self._lib.ppqc_set_tuning(self._ctx, name.encode(), int(value)))
 
     def bind_thread(self):
         """The context's GPU becomes the calling thread's current device (loader threads that allocate pinned memory)."""

@@ -16,10 +16,11 @@ ALPH = np.frombuffer(b"ACGTACGTNnacgtSs", np.uint8)
 @pytest.fixture(autouse=True, params=["0", "2", "1"], ids=["second_pass", "span_sums", "auto"])
 def line_sums_from(request, monkeypatch):
     """Every test runs both ways the line sums are made: the line-mode tile kernel's second pass over the text
-    (PPQC_FASTQ_SUMS=0), the span sums of the scan pass put together per line (2), and the library's own choice (1, the
-    default: by the mean line length of the context's previous text -- span sums for long lines, a scan that only counts
-    for very short ones).  The library reads the variable at every submit."""
-    monkeypatch.setenv("PPQC_FASTQ_SUMS", request.param)
+    (ppqc_set_tuning fastq_sums = 0), the span sums of the scan pass put together per line (2), and the library's own choice
+    (1, the default: by the mean line length of the context's previous text -- span sums for long lines, a scan that only
+    counts for very short ones)."""
+    from pypore_amd import qc
+    monkeypatch.setattr(qc.QCContext, "DEFAULT_TUNING", {"fastq_sums": int(request.param)})
     return request.param
 
 

@@ -8,7 +8,7 @@ from pypore_amd import qc, synth
 
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-variants = os.environ.get("AB_VARIANTS", "0,1,2,3,4,5").split(",")
+variants = os.environ.get("AB_VARIANTS", "0,0s,0d,0a,0p").split(",")
 bpcs = os.environ.get("AB_BPC", "0").split(",")
 shifts = os.environ.get("AB_SHIFT", "16").split(",")
 workload = os.environ.get("AB_WORKLOAD", "config2")
@@ -38,22 +38,18 @@ ref = None
 for rnd in range(rounds + 1):
     for v in variants:
         for bpc, sh in [(x, y) for x in bpcs for y in shifts]:
-            # "0" = the shipped pair of kernels (per-tile probe); "0s" / "0d" force every tile sparse / dense;
-            # "0a" / "0p": dense_kernel alone / always the pair; "0:LEN" sets the density threshold; "108" = the older one-kernel VECB instantiation
-            os.environ.pop("PPQC_TILE_DENSE", None); os.environ.pop("PPQC_TILE_DENSE_LEN", None)
-            os.environ.pop("PPQC_TILE_ALL", None)
-            vv = v
-            if v[0] == "0":      # "0<flags>[:LEN]"
-                vv = "0"
-                flags = v.split(":")[0][1:]
-                if "d" in flags: os.environ["PPQC_TILE_DENSE"] = "1"     # every tile onto the dense list
-                if "s" in flags: os.environ["PPQC_TILE_DENSE"] = "0"     # every tile sparse (tile_kernel alone)
-                if "a" in flags: os.environ["PPQC_TILE_ALL"] = "1"       # the dense kernel alone over every tile
-                if "p" in flags: os.environ["PPQC_TILE_ALL"] = "0"       # always the pair, whatever the mean
-                if ":" in v: os.environ["PPQC_TILE_DENSE_LEN"] = v.split(":")[1]
-            os.environ["PPQC_TILE_VARIANT"] = vv
-            os.environ["PPQC_TILE_BLOCKS_PER_CU"] = bpc
-            os.environ["PPQC_TILE_SHIFT"] = sh
+            # "0" = what ships (per-tile probe, or dense_kernel alone by the mean); "0s" / "0d" force every tile sparse /
+            # dense; "0a" / "0p": dense_kernel alone / always the pair; "0:LEN" sets the density threshold
+            tune = dict(tile_dense=-1, dense_len=-1, tile_all=-1)
+            flags = v.split(":")[0][1:]
+            if "d" in flags: tune["tile_dense"] = 1     # every tile onto the dense list
+            if "s" in flags: tune["tile_dense"] = 0     # every tile sparse (tile_kernel alone)
+            if "a" in flags: tune["tile_all"] = 1       # the dense kernel alone over every tile
+            if "p" in flags: tune["tile_all"] = 0       # always the pair, whatever the mean
+            if ":" in v: tune["dense_len"] = int(v.split(":")[1])
+            tune["tile_shift"] = int(sh)
+            for k, x in tune.items():
+                ctx.set_tuning(k, x)
             ctx.reset(); ctx.reset_timings()
             if sleep_ms: time.sleep(sleep_ms / 1e3)      # idle gap before the launch (clock / DPM effects)
             ctx.submit_device(R, nb, db.data_ptr(), dq.data_ptr(), *[x.data_ptr() for x in d])
