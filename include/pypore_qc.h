@@ -301,10 +301,21 @@ int ppqc_n50_select_pick(ppqc_ctx* ctx, int round);
  *   the context's stream waits for side; ppqc_finalize_extremes; ppqc_finalize_tables; all-reduce SUM of sum_buf;
  *   ppqc_fetch_tables
  * which leaves ONE collective behind the per-read kernel instead of four.  PPQC_E_STATE if the run does not qualify
- * (then use the phases above). */
+ * (then use the phases above).
+ * The (channel, mux, hour) cells -- 2 x n_channels x n_mux x n_time_bins words, all but a sliver of sum_buf: 13.8 of
+ * 13.9 MB at 3000 x 4 x 72 -- depend on the index alone as well, and the batches leave them with their index kernels.
+ * Between ppqc_stream_wait_index and the context's stream waiting for side:
+ *   ppqc_cells_early(ctx, 0, side)   the cells final in sum_buf[off_cmh_reads, n_sum) behind side
+ *   all-reduce SUM of that range on side
+ *   ppqc_cells_early(ctx, 1, side)   its copy to the host result buffer, on side
+ * and the all-reduce behind ppqc_finalize_tables then covers sum_buf[0, off_cmh_reads) only (a few thousand words), as
+ * does the copy of ppqc_fetch_tables.  Every rank may make these calls whenever ppqc_index_early says yes (a rank whose
+ * batches could not leave their cells -- 2^24 reads or 2^40 bases and more -- computes them inside the call, later).
+ * Not with PPQC_COMPAT_MULTI_READ_SINGLE (PPQC_E_STATE): that rule rewrites cells behind the tables. */
 int ppqc_index_early(ppqc_ctx* ctx, int* out);
 int ppqc_stream_wait_index(ppqc_ctx* ctx, void* stream);
 int ppqc_n50_select_early(ppqc_ctx* ctx, int round, int phase, void* stream);
+int ppqc_cells_early(ppqc_ctx* ctx, int phase, void* stream);
 
 /* time_mode 1 when the reads of a channel are spread over several GPUs (the reference's workers each hold one channel's
  * reads, lib/seq_routines.py:909-915, and apply the hour rule of lib/fast5_reader.py:117-126 to them in start-time

@@ -30,7 +30,7 @@ SYMBOLS = (
     "ppqc_sync", "ppqc_n_reads", "ppqc_read_stats", "ppqc_read_hours", "ppqc_finalize_extremes",
     "ppqc_finalize_tables", "ppqc_finalize_n50", "ppqc_fetch_tables", "ppqc_fetch_tables_view", "ppqc_finalize", "ppqc_finalize_view", "ppqc_device_tables_view",
     "ppqc_timings", "ppqc_reset_timings", "ppqc_sort_u32_device", "ppqc_sort_u32_device_static", "ppqc_synth_fill_device", "ppqc_fastq_scan", "ppqc_fastq_pack",
-    "ppqc_submit_fastq", "ppqc_submit_fastq_device", "ppqc_input_errors", "ppqc_time_range", "ppqc_set_ref_time", "ppqc_n50_select_hist", "ppqc_n50_select_pick", "ppqc_index_early", "ppqc_stream_wait_index", "ppqc_n50_select_early", "ppqc_set_stream",
+    "ppqc_submit_fastq", "ppqc_submit_fastq_device", "ppqc_input_errors", "ppqc_time_range", "ppqc_set_ref_time", "ppqc_n50_select_hist", "ppqc_n50_select_pick", "ppqc_index_early", "ppqc_stream_wait_index", "ppqc_n50_select_early", "ppqc_cells_early", "ppqc_set_stream",
     "ppqc_mode1_dist_view", "ppqc_mode1_dist_phase", "ppqc_slot_wait", "ppqc_compat_dist_count", "ppqc_bind_thread", "ppqc_set_tuning",
     "ppqc_group_create", "ppqc_group_finalize", "ppqc_group_destroy",
 )
@@ -150,6 +150,7 @@ def load():
         "ppqc_n50_select_hist": [P, C.c_int], "ppqc_n50_select_pick": [P, C.c_int],
         "ppqc_index_early": [P, C.POINTER(C.c_int)], "ppqc_stream_wait_index": [P, C.c_void_p],
         "ppqc_n50_select_early": [P, C.c_int, C.c_int, C.c_void_p],
+        "ppqc_cells_early": [P, C.c_int, C.c_void_p],
         "ppqc_set_stream": [P, P, C.c_int],
         "ppqc_group_create": [C.POINTER(P), C.POINTER(P), C.c_int], "ppqc_group_finalize": [P, C.POINTER(Tables)],
         "ppqc_group_destroy": [P],

@@ -90,6 +90,12 @@ struct EvPair {
 //                                                                                                           mirror's spare word)
 //   m1_phase      ppqc_mode1_dist_phase (0, 1, 2 in order)    finalize_extremes (-1), a reference time      finalize_tables (2: hours are done)
 //                                                              that changes (-1: the hours are stale)
+//   cells_early   ppqc_create / ppqc_reset (not with          a batch without index kernel, records / FASTQ  run_batch, finalize_tables, ppqc_cells_early
+//                 PPQC_COMPAT_MULTI_READ_SINGLE)              text, a run whose reads or bases may overflow
+//                                                              a packed cell
+//   cells_dirty   a batch that left cells                     every clear of the result buffer               finalize_tables (clears the region first)
+//   cells_done    ppqc_cells_early(0), ppqc_finalize          any new batch, ppqc_reset, a clear             finalize_tables (leaves the cells alone)
+//   cmh_on_host   ppqc_cells_early(1), ppqc_finalize          as cells_done                                  the result copies (small tables only)
 //   cc_ready      ppqc_compat_dist_count                      finalize_extremes                             finalize_tables (job-wide channel counts)
 //   fin_pending / end_split / fin_start / sort_start / sort_end: timing bookkeeping only (resolve_finalize_timings).
 //
@@ -166,6 +172,15 @@ struct ppqc_ctx {
     uint64_t* maxlen_host = nullptr;   // a few pinned scratch words (line count of the GPU tokenizer)
     uint64_t* m1 = nullptr;            // time_mode 1 across ranks: [first | ties | days] (ppqc_mode1_dist_view)
     int m1_phase = -1;                 // last phase of ppqc_mode1_dist_phase run since ppqc_finalize_extremes (2: hours done)
+    // The (channel, mux, hour) cells depend on the CSR index alone: a batch leaves them at submit time with its other
+    // index-only results (packed, one atomic per read), and whatever follows -- the unpack, the copy of the 2 x cells words
+    // to the host mirror, a caller's all-reduce -- can run beside the per-read kernel (ppqc_cells_early, finalize_impl).
+    uint64_t bases_total = 0;          // upper bound of the run's bases so far (cmh_packable)
+    bool cells_early = false;          // every batch since ppqc_reset left its cells
+    bool cells_dirty = false;          // some batch did: the region is not as the clear left it
+    bool cells_done = false;           // the cells are final and unpacked (no batch since): finalize_tables leaves them alone
+    bool cmh_on_host = false;          // ... and the host mirror holds them (behind ev_cmhcopy)
+    hipEvent_t ev_cells = nullptr, ev_cmhcopy = nullptr;
     uint64_t* cc = nullptr;            // PPQC_COMPAT_MULTI_READ_SINGLE across ranks: reads per channel (ppqc_compat_dist_count)
     bool cc_ready = false;             // ... counted since ppqc_finalize_extremes: ppqc_finalize_tables takes them as the job's
     ppqc_timing timing{};
@@ -354,6 +369,8 @@ static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_clean, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fq, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_hdr, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_cells, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_cmhcopy, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->ev_join));
     HIPCHK(hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
@@ -404,6 +421,7 @@ static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventRecord(c->ev_clean, c->stream));
     c->res_clean = true;
     c->pre_ok = true;
+    c->cells_early = !(cfg->compat_flags & PPQC_COMPAT_MULTI_READ_SINGLE);   // that rule rewrites cells behind the tables
     return PPQC_OK;
 }
 
@@ -453,6 +471,8 @@ int ppqc_destroy(ppqc_ctx* c) {
     if (c->ev_clean) (void)hipEventDestroy(c->ev_clean);
     if (c->ev_fq) (void)hipEventDestroy(c->ev_fq);
     if (c->ev_hdr) (void)hipEventDestroy(c->ev_hdr);
+    if (c->ev_cells) (void)hipEventDestroy(c->ev_cells);
+    if (c->ev_cmhcopy) (void)hipEventDestroy(c->ev_cmhcopy);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_reads) (void)hipEventDestroy(c->ev_reads);
@@ -490,6 +510,9 @@ int ppqc_reset(ppqc_ctx* c) {
     c->pre_ok = true;
     c->pre_run = false;
     c->n50_early = false;
+    c->bases_total = 0;
+    c->cells_early = !(c->cfg.compat_flags & PPQC_COMPAT_MULTI_READ_SINGLE);
+    c->cells_dirty = c->cells_done = c->cmh_on_host = false;
     return PPQC_OK;
 }
 
@@ -534,6 +557,11 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     c->pending.push_back(ev);
     const bool pre = c->pre_ok && c->res_clean && c->cfg.time_mode == 0 && c->tn.pre != 0;
     if (!pre) c->pre_ok = false;
+    // the batch's cells with its index kernel, as long as no packed cell of the run can overflow (host-known bounds)
+    const bool cells = pre && c->cells_early && cmh_packable(c->n_reads + R, c->bases_total + b->n_bytes);
+    if (!cells) c->cells_early = false;
+    c->bases_total += b->n_bytes;
+    c->cells_done = c->cmh_on_host = false;
     HIPCHK(launch_finalize_reads(v, c->ra, base, c->head, c->tail, c->tp.thr_fail, c->tp.fail_q,
                                  c->res_buf + c->res_words, c->cfg.n_channels, c->res_buf + c->res_words + 8, !pre, s));
     if (pre) {
@@ -543,7 +571,9 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
         // the main stream (ppqc_sync, the slots' reuse, a grow of the arrays) covers this kernel too.
         HIPCHK(hipStreamWaitEvent(c->aux, ev.a, 0));
         HIPCHK(launch_batch_extremes(v, base, c->ra, c->tp, c->max_buf, c->min_buf, c->tminmax,
-                                     c->res_buf + c->res_words + 4, c->maxlen_host + 4, c->aux));
+                                     c->res_buf + c->res_words + 4, c->maxlen_host + 4,
+                                     cells ? c->sum_buf + c->tp.lay.off_cmh_bases : nullptr, c->aux));
+        if (cells) c->cells_dirty = true;
         HIPCHK(hipEventRecord(c->ev_pre, c->aux));
         HIPCHK(hipStreamWaitEvent(s, c->ev_pre, 0));
     }
@@ -711,6 +741,8 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     c->state = 0;
     c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
     c->pre_ok = false;
+    c->cells_early = c->cells_done = c->cmh_on_host = false;
+    c->bases_total += n;     // the text holds every base
     if (n_records) *n_records = R;
     return PPQC_OK;
 }
@@ -776,6 +808,8 @@ int ppqc_submit_records(ppqc_ctx* c, const ppqc_records* r) {
     c->state = 0;
     c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
     c->pre_ok = false;
+    c->cells_early = c->cells_done = c->cmh_on_host = false;
+    for (uint64_t i = 0; i < n; ++i) c->bases_total += r->length[i];
     return PPQC_OK;
 }
 
@@ -917,12 +951,14 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
         c->init_on_aux = !c->res_busy;
         if (!c->res_busy) {
             HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, false, c->aux));
+            c->cells_dirty = c->cells_done = c->cmh_on_host = false;
             HIPCHK(hipEventRecord(c->ev_init, c->aux));
             HIPCHK(hipEventRecord(c->ev_t0, s));
             HIPCHK(hipStreamWaitEvent(s, c->ev_init, 0));
         } else {
             HIPCHK(hipEventRecord(c->ev_t0, s));
             HIPCHK(launch_init_results(c->res_buf, c->tp.lay.n_sum + PPQC_N_SEL, 1 + (uint64_t)c->cfg.n_channels, false, s));
+            c->cells_dirty = c->cells_done = c->cmh_on_host = false;
         }
     }
     c->res_clean = false;
@@ -983,7 +1019,23 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
         HIPCHK(sort_u64_pairs(c->sk64, c->sk64_tmp, c->vals, c->vals_tmp, n, c->counts, mask, s));
         HIPCHK(launch_mode1_hours(c->ra, n, c->tp, c->sk64, c->vals, c->chan_start, c->first_desc, s));
     }
-    HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, c->max_buf, s, c->cc_ready ? c->cc : nullptr));
+    // The cells: there already when every batch left them with its index kernel (then they are unpacked here unless
+    // ppqc_cells_early / ppqc_finalize has done that beside the per-read kernel); else by tables_kernel, one packed atomic
+    // per read when the run's reads and bases fit the two fields, into a region that is as the clear left it.
+    const uint64_t n_cells = (uint64_t)c->cfg.n_channels * c->cfg.n_mux * c->cfg.n_time_bins;
+    int cell_mode = 0;
+    if (!c->cells_done) {
+        if (c->pre_run && c->cells_early) {
+            HIPCHK(launch_cmh_unpack(c->tp, c->sum_buf, s));
+        } else {
+            if (c->cells_dirty) HIPCHK(hipMemsetAsync(c->sum_buf + c->tp.lay.off_cmh_reads, 0, 2 * n_cells * 8, s));
+            cell_mode = cmh_packable(n, c->bases_total) ? 1 : 2;
+        }
+        c->cells_dirty = false;
+        c->cells_done = true;
+        c->cmh_on_host = false;
+    }
+    HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, c->max_buf, s, cell_mode, c->cc_ready ? c->cc : nullptr));
     c->state = 2;
     if (c->n50_early) {   // the N50 is there already (ppqc_n50_select_early): the finalize ends here
         HIPCHK(hipEventRecord(c->ev_t1, s));
@@ -992,6 +1044,42 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
         c->state = 3;
     }
     return mark_busy(c);
+}
+
+// The result words the host reads ([sum | sel | max | min | time range | n50, total | select state | input errors]) to the
+// pinned mirror, on `st`.  When the mirror holds the cells already (cmh_on_host: 2 x cells words, by far the largest
+// part, copied beside the per-read kernel), only what lies in front of them and behind them is copied.
+static int copy_results(ppqc_ctx* c, hipStream_t st) {
+    const uint64_t end = c->res_words + 3;
+    if (!c->cmh_on_host) {
+        HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, end * 8, hipMemcpyDeviceToHost, st));
+        return PPQC_OK;
+    }
+    const uint64_t a = c->tp.lay.off_cmh_reads, b = c->tp.lay.n_sum + PPQC_N_SEL;   // the select histogram is not read either
+    HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, a * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->res_host + b, c->res_buf + b, (end - b) * 8, hipMemcpyDeviceToHost, st));
+    return PPQC_OK;
+}
+
+// The cells are final in the cmh region behind whatever `st` is ordered behind: unpack them there, and (to_host) copy the
+// region to the host mirror on `cs`, which waits for the unpack by event.
+static int cells_unpack_on(ppqc_ctx* c, hipStream_t st) {
+    HIPCHK(launch_cmh_unpack(c->tp, c->sum_buf, st));
+    c->cells_dirty = false;
+    c->cells_done = true;
+    c->cmh_on_host = false;
+    return PPQC_OK;
+}
+static int cells_to_host_on(ppqc_ctx* c, hipStream_t st, hipStream_t cs) {
+    const uint64_t n_cells = (uint64_t)c->cfg.n_channels * c->cfg.n_mux * c->cfg.n_time_bins, a = c->tp.lay.off_cmh_reads;
+    if (cs != st) {
+        HIPCHK(hipEventRecord(c->ev_cells, st));
+        HIPCHK(hipStreamWaitEvent(cs, c->ev_cells, 0));
+    }
+    HIPCHK(hipMemcpyAsync(c->res_host + a, c->res_buf + a, 2 * n_cells * 8, hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipEventRecord(c->ev_cmhcopy, cs));
+    c->cmh_on_host = true;
+    return PPQC_OK;
 }
 
 static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, bool early_fetch) {
@@ -1042,7 +1130,7 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     if (ss == s) HIPCHK(hipEventRecord(c->ev_s1, ss));
     if (ss != s) {
         if (early_out) {   // ppqc_finalize: all but the N50 is final behind the tables kernel; copied beside the sort chain
-            HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, (c->res_words + 3) * 8, hipMemcpyDeviceToHost, s));
+            CHK(copy_results(c, s));
             c->sum_fetched = true;
         }
         HIPCHK(hipEventRecord(c->ev_join, ss));   // also the end of the sort timing
@@ -1066,10 +1154,10 @@ static int fetch_tables_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
     const TableLayout& l = c->tp.lay;
     // stream-ordered behind the last finalize kernel: one host synchronisation for the whole step
     const bool n50_in_mirror = c->sum_fetched;
-    if (!c->sum_fetched)
-        HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, (c->res_words + 3) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (!c->sum_fetched) CHK(copy_results(c, c->stream));
     c->sum_fetched = false;
     CHK(ppqc_sync(c));
+    if (c->cmh_on_host) HIPCHK(hipEventSynchronize(c->ev_cmhcopy));   // the cells' copy ran on another stream
     {   // the device keeps the minima complemented (one all-reduce MAX merges maxima and minima): decode in place
         uint64_t* mnw = c->res_host + c->tp.lay.n_sum + PPQC_N_SEL + 1 + (uint64_t)c->tp.lay.n_channels;
         for (uint64_t k = 0; k < 1 + (uint64_t)c->tp.lay.n_channels; ++k) mnw[k] = ~mnw[k];
@@ -1110,6 +1198,13 @@ int ppqc_fetch_tables_view(ppqc_ctx* c, ppqc_tables* o) { return fetch_tables_im
 
 static int finalize_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
     CHK(ppqc_finalize_extremes(c));
+    // Every batch left its cells with its index kernel: unpack them on the auxiliary stream, right behind those kernels,
+    // and copy the region (13.8 MB at 3000 x 4 x 72, the bulk of the result buffer) to the host mirror on a copy stream --
+    // all of it beside the per-read kernel, which this call usually finds running.
+    if (c->pre_run && c->cells_early && !c->cells_done) {
+        CHK(cells_unpack_on(c, c->aux));
+        CHK(cells_to_host_on(c, c->aux, c->copy[1]));
+    }
     CHK(ppqc_finalize_tables(c));
     CHK(finalize_n50_impl(c, nullptr, 0, true));
     return fetch_tables_impl(c, o, view);
@@ -1200,6 +1295,37 @@ int ppqc_n50_select_early(ppqc_ctx* c, int round, int phase, void* stream) {
         HIPCHK(launch_select_pick(c->sel_buf, nullptr, c->sel_state, kSelShift[round], kSelBits[round], round == 2,
                                   round == 0, c->n50_out, ss));
         if (round == 2) c->n50_early = true;
+    }
+    return mark_busy(c);
+}
+
+int ppqc_cells_early(ppqc_ctx* c, int phase, void* stream) {
+    if (!c) return fail(PPQC_E_INVALID, "null context");
+    if (phase < 0 || phase > 1) return fail(PPQC_E_INVALID, "phase must be 0 or 1");
+    if (c->cfg.compat_flags & PPQC_COMPAT_MULTI_READ_SINGLE)
+        return fail(PPQC_E_STATE, "ppqc_cells_early: PPQC_COMPAT_MULTI_READ_SINGLE rewrites cells behind the tables");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t ss = (hipStream_t)stream;
+    if (phase == 0) {
+        if (!(c->pre_ok && c->res_clean && c->cfg.time_mode == 0))
+            return fail(PPQC_E_STATE, "the run's batches did not leave their index-only results at submit time");
+        if (c->cells_early) {
+            CHK(cells_unpack_on(c, ss));
+        } else {
+            // A batch could not leave its cells (the run's reads or bases may overflow a packed cell).  Every rank of a
+            // job must make the same calls whatever its data, so this call still leaves the cells, later: behind the
+            // per-read kernels, from the run's arrays.
+            const uint64_t n_cells = (uint64_t)c->cfg.n_channels * c->cfg.n_mux * c->cfg.n_time_bins;
+            if (c->n_reads) HIPCHK(hipStreamWaitEvent(ss, c->ev_reads, 0));
+            HIPCHK(hipMemsetAsync(c->sum_buf + c->tp.lay.off_cmh_reads, 0, 2 * n_cells * 8, ss));
+            HIPCHK(launch_cells(c->ra, c->n_reads, c->tp, c->sum_buf, ss));
+            c->cells_dirty = false;
+            c->cells_done = true;
+            c->cmh_on_host = false;
+        }
+    } else {
+        if (!c->cells_done) return fail(PPQC_E_STATE, "ppqc_cells_early: phase 0 first");
+        CHK(cells_to_host_on(c, ss, ss));
     }
     return mark_busy(c);
 }

@@ -111,11 +111,18 @@ hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uin
                            int64_t* tminmax, bool write_lens, hipStream_t s);
 hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays ra, const TableParams& tp,
                                  uint64_t* max_buf, uint64_t* min_buf, int64_t* tminmax, uint64_t* bound,
-                                 uint64_t* bound_host, hipStream_t s);   // at submit time, beside the tile kernel
+                                 uint64_t* bound_host, uint64_t* cells, hipStream_t s);   // at submit time, beside the tile
+                                 // kernel; cells != nullptr: the batch's packed (channel, mux, hour) cells too (cmh_bases region)
+// (channel, mux, hour) cells: one packed atomic per read when the run's reads and bases (host-known) fit the two fields
+bool cmh_packable(uint64_t n_reads, uint64_t n_bases);
+hipError_t launch_cmh_unpack(const TableParams& tp, uint64_t* sum_buf, hipStream_t s);
+hipError_t launch_cells(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, hipStream_t s);   // unpacked, region zero
 // job_chan_count: per-channel read count of the whole multi-GPU job for PPQC_COMPAT_MULTI_READ_SINGLE (nullptr: this
 // rank's own table is the job's)
+// cell_mode 0: the cells are in sum_buf already (left at submit time; the caller unpacks them), 1: one packed atomic
+// per read + cmh_unpack, 2: two atomics per read
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
-                         hipStream_t s, const uint64_t* job_chan_count = nullptr);
+                         hipStream_t s, int cell_mode, const uint64_t* job_chan_count = nullptr);
 hipError_t launch_chan_count(ReadArrays ra, uint64_t n, uint32_t n_channels, uint64_t* out, hipStream_t s);
 
 hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s);

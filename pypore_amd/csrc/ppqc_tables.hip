@@ -29,11 +29,17 @@ __device__ __forceinline__ int32_t hour_of_day(int64_t t, const TableParams& tp)
 // accumulates into the buffers ppqc_reset cleared, writes lens32 / hour of the batch's reads (run index base + i), and
 // the block that draws the last ticket (bound[1]) stores the run's largest key so far (max_buf[0]) into the pinned
 // host word: the host then knows how many radix passes the N50 sort needs.
+// `cells` (BATCH only): the (channel, mux, hour) cells of the batch's reads as well -- they, too, depend on the index
+// alone (channel, mux, start time, length) -- one packed atomic per read, count above bit kCmhShift (cmh_unpack_kernel
+// splits the cells; the host checks at finalize time that no field can have overflowed, cmh_packable).  These atomics
+// execute at the memory side at about 20 per ns for the whole chip, whoever issues them: issued here they cost the
+// per-read kernel beside them nothing, issued by tables_kernel they were two thirds of the step's tail at 4 * 10^6 reads.
+constexpr int kCmhShift = 40;
 template <bool BATCH>
 __global__ __launch_bounds__(1024) void extremes_kernel(BatchView b, uint64_t base, ReadArrays ra, uint64_t n,
                                                        TableParams tp, uint64_t* max_buf, uint64_t* min_buf,
                                                        int64_t* tminmax, uint32_t nchL, int write_lens, uint64_t* bound,
-                                                       uint64_t* __restrict__ bound_host) {
+                                                       uint64_t* __restrict__ bound_host, uint64_t* cells) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* s_cmax = reinterpret_cast<uint32_t*>(smem);
     uint32_t* s_cmin = s_cmax + nchL;
@@ -87,6 +93,12 @@ __global__ __launch_bounds__(1024) void extremes_kernel(BatchView b, uint64_t ba
             }
         }
         if (tp.time_mode == 0) ra.hour[g] = hour;
+        if (BATCH && cells != nullptr && hour >= 0) {   // hour >= 0: channel and start time are good, time_mode is 0
+            const uint32_t m = b.mux[i];
+            if (m >= 1 && m <= tp.lay.n_mux)
+                atomicAdd((unsigned long long*)&cells[((uint64_t)(ch - 1) * tp.lay.n_mux + (m - 1)) * tp.lay.n_time_bins + (uint32_t)hour],
+                          (1ull << kCmhShift) | (unsigned long long)L);
+        }
     }
     if (lmax) atomicMax(&s_max, lmax);
     if (lmin != (unsigned long long)INT64_MAX) atomicMin(&s_min, lmin);
@@ -115,19 +127,15 @@ __global__ __launch_bounds__(1024) void extremes_kernel(BatchView b, uint64_t ba
     }
 }
 
-// The (channel, mux, hour) cells take two device-scope atomics per read (reads += 1, bases += L), 62 of the kernel's 115 us
-// at 10^6 reads.  When no cell can overflow either field -- n < 2^22 reads and n * max_len < 2^42 bases, decided on the
-// device from the run's max_len -- both go into ONE atomic on the bases cell, the count above bit 42, and
-// cmh_unpack_kernel splits the cells afterwards.  Exact by construction: a cell's count is at most n, its bases at most
-// n * max_len.
-constexpr int kCmhShift = 42;
-__device__ __forceinline__ bool cmh_packable(uint64_t n, uint64_t max_len) {
-    return n < (1ull << (64 - kCmhShift)) && (max_len == 0 || n <= ((1ull << kCmhShift) - 1) / max_len);
+// The (channel, mux, hour) cells take two device-scope atomics per read (reads += 1, bases += L).  When no cell can
+// overflow either field -- fewer than 2^24 reads and fewer than 2^40 bases in the run, which the host knows -- both go into
+// ONE atomic on the bases cell, the count above bit kCmhShift, and cmh_unpack_kernel splits the cells afterwards.  Exact
+// by construction: a cell's count is at most the run's reads, its bases at most the run's bases.
+bool cmh_packable(uint64_t n_reads, uint64_t n_bases) {
+    return n_reads < (1ull << (64 - kCmhShift)) && n_bases < (1ull << kCmhShift);
 }
 
-__global__ __launch_bounds__(256) void cmh_unpack_kernel(uint64_t* sum_buf, TableLayout lay, uint64_t n,
-                                                         const uint64_t* max_buf) {
-    if (!cmh_packable(n, max_buf[0])) return;
+__global__ __launch_bounds__(256) void cmh_unpack_kernel(uint64_t* sum_buf, TableLayout lay) {
     const uint64_t cells = (uint64_t)lay.n_channels * lay.n_mux * lay.n_time_bins;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t v = sum_buf[lay.off_cmh_bases + i];
@@ -187,8 +195,9 @@ __global__ __launch_bounds__(256) void chan_count_kernel(const uint32_t* __restr
 //   u64 totals[16] | u64 hour_bases[nb] | u64 chan_bases[nchL] |
 //   u32 len_log2[40] | u32 len_lin[100] | u32 q[8] | u32 gc[20] | u32 hour_reads[nb] | u32 chan_reads[nchL] | u32 chan_fail[nchL]
 // nchL = n_channels when the per-channel accumulators fit in LDS, else 0 (then they go straight to global atomics).
+// cell_mode: 0 the cells are there already (every batch left them at submit time), 1 one packed atomic per read, 2 two.
 __global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf,
-                                                     const uint64_t* max_buf, uint32_t nchL) {
+                                                     const uint64_t* max_buf, uint32_t nchL, int cell_mode) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t nb = tp.lay.n_time_bins, nch = tp.lay.n_channels, nmux = tp.lay.n_mux;
     unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(smem);
@@ -209,7 +218,6 @@ __global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n,
 
     unsigned long long* g = reinterpret_cast<unsigned long long*>(sum_buf);
     const uint64_t lin_w = max_buf[0] / PPQC_N_LEN_LIN + 1;
-    const bool packed = cmh_packable(n, max_buf[0]);
     const bool chan_lds = nchL != 0;
 
     uint64_t tot[PPQC_TOT_NO_TIME + 1] = {};   // thread-local run totals, added to LDS once at the end
@@ -262,7 +270,8 @@ __global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n,
         atomicAdd(&s_hreads[h], 1u);
         atomicAdd(&s_hbases[h], (unsigned long long)L);
         const uint64_t cell = ((uint64_t)c * nmux + (m - 1)) * nb + (uint32_t)h;
-        if (packed) {   // one atomic per read: count in the bits above kCmhShift (cmh_unpack_kernel splits the cells)
+        if (cell_mode == 0) continue;
+        if (cell_mode == 1) {   // one atomic per read: count in the bits above kCmhShift (cmh_unpack_kernel splits the cells)
             atomicAdd(&g[tp.lay.off_cmh_bases + cell], (1ull << kCmhShift) | (unsigned long long)L);
         } else {
             atomicAdd(&g[tp.lay.off_cmh_reads + cell], 1ull);
@@ -427,14 +436,15 @@ hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uin
     const uint32_t nchL = tp.lay.n_channels <= kExtremesLdsChannels ? tp.lay.n_channels : 0;
     hipLaunchKernelGGL(extremes_kernel<false>, dim3(grid_for(n, 256)),
                        dim3(512), (size_t)nchL * 8, s, BatchView{}, (uint64_t)0, ra, n, tp,
-                       max_buf, min_buf, tminmax, nchL, write_lens ? 1 : 0, (uint64_t*)nullptr, (uint64_t*)nullptr);
+                       max_buf, min_buf, tminmax, nchL, write_lens ? 1 : 0, (uint64_t*)nullptr, (uint64_t*)nullptr,
+                       (uint64_t*)nullptr);
     return hipGetLastError();
 }
 
 // The same for one batch at submit time (see extremes_kernel<true>); bound[1] must be zero between launches.
 hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays ra, const TableParams& tp,
                                  uint64_t* max_buf, uint64_t* min_buf, int64_t* tminmax, uint64_t* bound,
-                                 uint64_t* bound_host, hipStream_t s) {
+                                 uint64_t* bound_host, uint64_t* cells, hipStream_t s) {
     if (b.n_reads == 0) return hipSuccess;
     const uint32_t nchL = tp.lay.n_channels <= kExtremesLdsChannels ? tp.lay.n_channels : 0;
     // A small grid on purpose: the tile kernel fills every SIMD's registers (4 waves of 128), so each wave resident
@@ -443,7 +453,7 @@ hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays r
     // nothing (2048 waves of 8 reads each cost config 2 about 15 us of tile-kernel time).
     hipLaunchKernelGGL(extremes_kernel<true>, dim3(grid_for(b.n_reads, 64)),
                        dim3(256), (size_t)nchL * 8, s, b, base, ra, b.n_reads, tp, max_buf,
-                       min_buf, tminmax, nchL, 1, bound, bound_host);
+                       min_buf, tminmax, nchL, 1, bound, bound_host, cells);
     return hipGetLastError();
 }
 
@@ -454,8 +464,33 @@ hipError_t launch_chan_count(ReadArrays ra, uint64_t n, uint32_t n_channels, uin
     return hipGetLastError();
 }
 
+// The cells alone from the run's per-read arrays (two atomics per read): what ppqc_cells_early falls back to when a
+// batch could not leave its cells at submit time.  The region must be zero.
+__global__ __launch_bounds__(256) void cells_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf) {
+    unsigned long long* g = reinterpret_cast<unsigned long long*>(sum_buf);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t chn = ra.channel[i], m = ra.mux[i];
+        const int32_t h = ra.hour[i];
+        if (chn < 1 || chn > tp.lay.n_channels || m < 1 || m > tp.lay.n_mux || h < 0 || h >= (int32_t)tp.lay.n_time_bins) continue;
+        const uint64_t cell = ((uint64_t)(chn - 1) * tp.lay.n_mux + (m - 1)) * tp.lay.n_time_bins + (uint32_t)h;
+        atomicAdd(&g[tp.lay.off_cmh_reads + cell], 1ull);
+        atomicAdd(&g[tp.lay.off_cmh_bases + cell], (unsigned long long)ra.len[i]);
+    }
+}
+hipError_t launch_cells(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(cells_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, s, ra, n, tp, sum_buf);
+    return hipGetLastError();
+}
+
+hipError_t launch_cmh_unpack(const TableParams& tp, uint64_t* sum_buf, hipStream_t s) {
+    const uint64_t cells = (uint64_t)tp.lay.n_channels * tp.lay.n_mux * tp.lay.n_time_bins;
+    hipLaunchKernelGGL(cmh_unpack_kernel, dim3(grid_for(cells, 512)), dim3(256), 0, s, sum_buf, tp.lay);
+    return hipGetLastError();
+}
+
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
-                         hipStream_t s, const uint64_t* job_chan_count) {
+                         hipStream_t s, int cell_mode, const uint64_t* job_chan_count) {
     if (n == 0) return hipSuccess;
     const uint32_t nb = tp.lay.n_time_bins;
     // per-channel accumulators in LDS need 16 B per channel; keep the block under 64 KiB so 2 blocks fit a CU.  When
@@ -472,9 +507,11 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
     // few, fat blocks: every block flushes its private tables once (measured on MI355X, config 2: 256 x 512 threads
     // 0.317 ms for the whole finalize, 512 x 256: 0.34, 2048 x 256: 0.42)
     hipLaunchKernelGGL(tables_kernel, dim3(grid_for(n, 256)),
-                       dim3(512), lds, s, ra, n, tp, sum_buf, max_buf, nchL);
-    const uint64_t cells = (uint64_t)tp.lay.n_channels * tp.lay.n_mux * tp.lay.n_time_bins;
-    hipLaunchKernelGGL(cmh_unpack_kernel, dim3(grid_for(cells, 512)), dim3(256), 0, s, sum_buf, tp.lay, n, max_buf);
+                       dim3(512), lds, s, ra, n, tp, sum_buf, max_buf, nchL, cell_mode);
+    if (cell_mode == 1) {
+        const hipError_t e = launch_cmh_unpack(tp, sum_buf, s);
+        if (e != hipSuccess) return e;
+    }
     if (tp.compat_flags & PPQC_COMPAT_MULTI_READ_SINGLE)
         hipLaunchKernelGGL(compat_single_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ra, n, tp, sum_buf,
                            job_chan_count);

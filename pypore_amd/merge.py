@@ -12,9 +12,11 @@ FastStats (lib/seq_routines.py:103-108):
      minima bitwise complemented so that they merge by MAX too)
   2. exact N50 by weighted radix select: three 2048-word histograms, each all-reduced between its histogram and its
      pick (the alternative n50="gather" all-gathers the u32 lengths and sorts them on every rank)
+  3. all-reduce SUM on the (channel, mux, hour) cells, which are index-only too and all but a sliver of the table buffer
+     (1.5 MB at 512x4x48, 13.8 MB at 3000x4x72) -- one call; at these sizes the ring is latency-bound on xGMI, so it is
+     not bucketed or pipelined -- and their copy to the host
   behind it:
-  3. all-reduce SUM on the fused u64 table buffer (1.6 MB at 512x4x48, 13.9 MB at 3000x4x72) -- one call; at these
-     sizes the ring is latency-bound on xGMI, so it is not bucketed or pipelined
+  4. all-reduce SUM on the rest of the table buffer (histograms, per-hour and per-channel tables: a few thousand words)
   (early=False, or a context that cannot tell its index-only results early: the same merges as four collectives behind
   the kernel, the first select histogram fused into the table buffer's all-reduce)
 

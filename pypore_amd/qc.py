@@ -283,6 +283,11 @@ class QCContext:
         """Histogram (phase 0) / pick (phase 1) of select round ``rnd`` on a caller's stream, independent of the tables."""
         L.check(self._lib.ppqc_n50_select_early(self._ctx, int(rnd), int(phase), C.c_void_p(int(stream_handle))))
 
+    def cells_early(self, phase, stream_handle):
+        """The (channel, mux, hour) cells on a caller's stream, beside the per-read kernel: phase 0 leaves them final in
+        the ``cmh`` view of ``device_tables`` (for the all-reduce), phase 1 copies them to the host result buffer."""
+        L.check(self._lib.ppqc_cells_early(self._ctx, int(phase), C.c_void_p(int(stream_handle))))
+
     def n50_select(self):
         """Single-GPU run of the multi-GPU N50 path (three histogram / pick rounds, no collectives in between)."""
         for r in range(3):
@@ -318,7 +323,10 @@ class QCContext:
                      maxmin=DeviceArrayView(d.max_buf, d.n_max + d.n_min, "<i8", self),
                      lengths=DeviceArrayView(d.lengths, d.n_lengths, "<i4", self),
                      sel=DeviceArrayView(d.sel_buf, d.n_sel, "<i8", self),
-                     sum_sel=DeviceArrayView(d.sum_buf, d.n_sum + d.n_sel, "<i8", self))
+                     sum_sel=DeviceArrayView(d.sum_buf, d.n_sum + d.n_sel, "<i8", self),
+                     # [small | cmh] = sum: the cells are all but a sliver of it and can be merged early (cells_early)
+                     small=DeviceArrayView(d.sum_buf, d.off_cmh_reads, "<i8", self),
+                     cmh=DeviceArrayView((d.sum_buf or 0) + 8 * d.off_cmh_reads, d.n_sum - d.off_cmh_reads, "<i8", self))
         return views, d
 
     def mode1_dist_tables(self):
