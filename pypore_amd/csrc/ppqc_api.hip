@@ -106,6 +106,8 @@ struct ppqc_ctx {
     Tuning tn{};   // ppqc_set_tuning: all -1 (the library's own choices) unless a test or a measurement says otherwise
     ppqc_config cfg{};
     TableParams tp{};
+    QThr qthr{};
+    uint64_t* tab_slab = nullptr;   // tables_kernel: one slab of private tables per block (tables_slab_words)
     hipStream_t stream = nullptr, own_stream = nullptr, copy[2] = {nullptr, nullptr};
     hipStream_t aux = nullptr;      // the sort + N50 chain runs here, beside the tables kernel on `stream`
     hipEvent_t ev_join = nullptr, ev_init = nullptr;
@@ -392,8 +394,11 @@ static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     make_layout(*cfg, &tp.lay);
     tp.bin_seconds = cfg->bin_seconds; tp.time_mode = cfg->time_mode; tp.tz_offset_s = cfg->tz_offset_s;
     tp.compat_flags = cfg->compat_flags;
-    tp.ref_time_s = cfg->ref_time_s; tp.fail_q = cfg->fail_q; tp.thr_fail = q_threshold(cfg->fail_q);
-    for (int j = 0; j <= PPQC_N_QHIST; ++j) tp.thr_q[j] = q_threshold(6.0 + j);
+    tp.ref_time_s = cfg->ref_time_s; tp.fail_q = cfg->fail_q;
+    c->qthr.fail = q_threshold(cfg->fail_q);
+    c->qthr.fail_q = cfg->fail_q;
+    for (int j = 0; j <= PPQC_N_QHIST; ++j) c->qthr.q[j] = q_threshold(6.0 + j);
+    HIPCHK(hipMalloc((void**)&c->tab_slab, tables_slab_words(tp.lay) * 8));
 
     const uint64_t nch1 = 1 + (uint64_t)cfg->n_channels;
     c->res_words = tp.lay.n_sum + PPQC_N_SEL + 2 * nch1 + 8;
@@ -462,7 +467,7 @@ int ppqc_destroy(ppqc_ctx* c) {
     void* ptrs[] = {r.rec_cnt, r.rec_hi, r.rec_lo, r.len, r.gc, r.nn, r.qsum, r.mean_q, r.err_hi, r.err_lo, r.flags,
                     r.channel, r.mux, r.time, r.hour, r.lens32, c->head, c->tail, c->res_buf, c->sk32, c->sk32_tmp, c->counts, c->vals, c->vals_tmp, c->sk64,
                     c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev, c->dense.base, c->fq.counts, c->fq.n_entries, c->fq.entries, c->fq.prefix,
-                    c->fq.block_sums, c->fq.line_off, c->fq.span_sum, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo, c->m1, c->cc};
+                    c->fq.block_sums, c->fq.line_off, c->fq.span_sum, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo, c->m1, c->cc, c->tab_slab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->maxlen_host) (void)hipHostFree(c->maxlen_host);
@@ -562,7 +567,7 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     if (!cells) c->cells_early = false;
     c->bases_total += b->n_bytes;
     c->cells_done = c->cmh_on_host = false;
-    HIPCHK(launch_finalize_reads(v, c->ra, base, c->head, c->tail, c->tp.thr_fail, c->tp.fail_q,
+    HIPCHK(launch_finalize_reads(v, c->ra, base, c->head, c->tail, c->qthr,
                                  c->res_buf + c->res_words, c->cfg.n_channels, c->res_buf + c->res_words + 8, !pre, s));
     if (pre) {
         // Enqueued behind the batch's kernels in host order (every call in front of the tile kernel's launch delays its
@@ -736,7 +741,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     }
     if (hdr_aux) HIPCHK(hipStreamWaitEvent(s, c->ev_hdr, 0));
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
-                                 c->lut_dev, c->tp.thr_fail, c->tp.fail_q, mux, c->res_buf + c->res_words, s, from_sums));
+                                 c->lut_dev, c->qthr, mux, c->res_buf + c->res_words, s, from_sums));
     c->n_reads += R;
     c->state = 0;
     c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
@@ -907,6 +912,8 @@ int ppqc_read_stats(ppqc_ctx* c, const ppqc_per_read* o, uint64_t first, uint64_
     D2H(o->qsum, r.qsum, int64_t); D2H(o->mean_q, r.mean_q, double); D2H(o->err_hi, r.err_hi, uint64_t);
     D2H(o->err_lo, r.err_lo, uint64_t); D2H(o->flags, r.flags, uint8_t);
 #undef D2H
+    if (o->flags)   // the device keeps the read's quality bin in the upper bits (quality_flags)
+        for (uint64_t i = 0; i < n; ++i) o->flags[i] &= kFlagsPublic;
     return PPQC_OK;
 }
 
@@ -1035,7 +1042,7 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
         c->cells_done = true;
         c->cmh_on_host = false;
     }
-    HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, c->max_buf, s, cell_mode, c->cc_ready ? c->cc : nullptr));
+    HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, c->max_buf, c->tab_slab, s, cell_mode, c->cc_ready ? c->cc : nullptr));
     c->state = 2;
     if (c->n50_early) {   // the N50 is there already (ppqc_n50_select_early): the finalize ends here
         HIPCHK(hipEventRecord(c->ev_t1, s));

@@ -702,8 +702,8 @@ __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __re
                                                              ReadArrays lra, ReadArrays ra, uint64_t read_base,
                                                              const Partial* __restrict__ head,
                                                              const Partial* __restrict__ tail, uint32_t tile_shift,
-                                                             const uint64_t* __restrict__ lut, uint64_t thr_fail,
-                                                             double fail_q, uint8_t mux, uint64_t* __restrict__ errors) {
+                                                             const uint64_t* __restrict__ lut, QThr thr,
+                                                             uint8_t mux, uint64_t* __restrict__ errors) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_records) return;
     const uint64_t g = read_base + r;
@@ -766,14 +766,8 @@ __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __re
     const uint64_t Lr = ok ? L : 0;
     uint8_t flags = 0;
     double mq = 0.0;
-    if (Lr != 0) {
-        const double S = (double)hi * 4294967296.0 + (double)lw;
-        mq = -10.0 * log10(S / ((double)Lr * 4503599627370496.0));
-        const unsigned __int128 S128 = ((unsigned __int128)hi << 32) + lw;
-        flags = S128 > (unsigned __int128)Lr * thr_fail ? 1 : 0;
-    } else {
-        flags = 0.0 < fail_q ? 1 : 0;
-    }
+    if (Lr != 0) flags = quality_flags(Lr, hi, lw, thr, &mq);
+    else flags = 0.0 < thr.fail_q ? 1 : 0;
     ra.len[g] = (uint32_t)Lr; ra.gc[g] = (uint32_t)gcs; ra.nn[g] = (uint32_t)nn;
     ra.qsum[g] = (int64_t)qb - 33 * (int64_t)Lr;
     ra.err_hi[g] = hi; ra.err_lo[g] = lw;
@@ -795,16 +789,16 @@ hipError_t launch_fastq_header(const uint8_t* text, uint64_t n_records, const ui
 
 hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
                                  ReadArrays line_ra, ReadArrays ra, uint64_t read_base, const Partial* head,
-                                 const Partial* tail, uint32_t tile_shift, const uint64_t* lut, uint64_t thr_fail,
-                                 double fail_q, uint8_t mux, uint64_t* errors, hipStream_t s, bool whole_lines) {
+                                 const Partial* tail, uint32_t tile_shift, const uint64_t* lut, const QThr& thr,
+                                 uint8_t mux, uint64_t* errors, hipStream_t s, bool whole_lines) {
     if (n_records == 0) return hipSuccess;
     if (whole_lines)
         hipLaunchKernelGGL(fastq_finalize_kernel<true>, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n,
-                           n_records, line_off, line_ra, ra, read_base, head, tail, tile_shift, lut, thr_fail, fail_q, mux,
+                           n_records, line_off, line_ra, ra, read_base, head, tail, tile_shift, lut, thr, mux,
                            errors);
     else
         hipLaunchKernelGGL(fastq_finalize_kernel<false>, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n,
-                           n_records, line_off, line_ra, ra, read_base, head, tail, tile_shift, lut, thr_fail, fail_q, mux,
+                           n_records, line_off, line_ra, ra, read_base, head, tail, tile_shift, lut, thr, mux,
                            errors);
     return hipGetLastError();
 }

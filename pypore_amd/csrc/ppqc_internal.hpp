@@ -70,10 +70,19 @@ struct TableParams {
     uint32_t compat_flags;
     int64_t tz_offset_s;
     int64_t ref_time_s;
-    uint64_t thr_fail;         // fixed-point image of fail_q
-    uint64_t thr_q[PPQC_N_QHIST + 1];   // images of 6,7,...,14
     double fail_q;
 };
+
+// Fixed-point images of the quality thresholds (finalize_reads_kernel, fastq_finalize_kernel)
+struct QThr {
+    uint64_t fail;                    // image of fail_q
+    uint64_t q[PPQC_N_QHIST + 1];     // images of 6, 7, ..., 14
+    double fail_q;
+};
+// per-read flags on the device: bits 0..2 as in ppqc_per_read.flags; bits 4..7 = 1 + the read's bin of the quality
+// histogram (0: none), left by whoever computes the read's mean quality so that tables_kernel needs neither the error
+// sum nor any 128-bit arithmetic.  ppqc_read_stats hands out bits 0..3 only.
+constexpr uint8_t kFlagsPublic = 0x0F;
 
 // ---- launchers (each enqueues on `s`, returns the hipError of the launch) -----------------------------------------
 // Device list of the dense tiles of one launch with two sets of counters used alternately: launch k
@@ -99,7 +108,7 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
                               Partial* head, Partial* tail, DenseList& dl, const Tuning& tn, hipStream_t s,
                               bool line_mode = false);
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
-                                 const Partial* tail, uint64_t thr_fail, double fail_q, uint64_t* csr_errors,
+                                 const Partial* tail, const QThr& thr, uint64_t* csr_errors,
                                  uint32_t n_channels, uint64_t* gate, bool write_lens, hipStream_t s);
 
 // Pre-computed reads (sequencing_summary.txt rows): device arrays of n entries appended at read_base.
@@ -121,8 +130,10 @@ hipError_t launch_cells(ReadArrays ra, uint64_t n, const TableParams& tp, uint64
 // rank's own table is the job's)
 // cell_mode 0: the cells are in sum_buf already (left at submit time; the caller unpacks them), 1: one packed atomic
 // per read + cmh_unpack, 2: two atomics per read
+// slab: tables_slab_words(layout) u64 of scratch (every block leaves its private tables there; a second kernel adds them up)
+uint64_t tables_slab_words(const TableLayout& lay);
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
-                         hipStream_t s, int cell_mode, const uint64_t* job_chan_count = nullptr);
+                         uint64_t* slab, hipStream_t s, int cell_mode, const uint64_t* job_chan_count = nullptr);
 hipError_t launch_chan_count(ReadArrays ra, uint64_t n, uint32_t n_channels, uint64_t* out, hipStream_t s);
 
 hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s);
@@ -199,8 +210,8 @@ hipError_t launch_fastq_header(const uint8_t* text, uint64_t n_records, const ui
                                uint64_t read_base, uint8_t mux, hipStream_t s);
 hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
                                  ReadArrays line_ra, ReadArrays ra, uint64_t read_base, const Partial* head,
-                                 const Partial* tail, uint32_t tile_shift, const uint64_t* lut, uint64_t thr_fail,
-                                 double fail_q, uint8_t mux, uint64_t* errors, hipStream_t s, bool whole_lines = false);
+                                 const Partial* tail, uint32_t tile_shift, const uint64_t* lut, const QThr& thr,
+                                 uint8_t mux, uint64_t* errors, hipStream_t s, bool whole_lines = false);
 
 hipError_t launch_synth(uint8_t* bases, uint8_t* quals, uint64_t first, uint64_t n, uint64_t seed, hipStream_t s);
 
@@ -295,6 +306,29 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
     return ((uint64_t)hi << 32) | lo;
+}
+
+// Mean quality of a read of L > 0 bytes whose fixed-point error sum is S = H * 2^32 + l32, and the flags that hang on it:
+// bit 0 = fail (mean_q < fail_q <=> S > L * e(fail_q), exact integers), bits 4..7 = 1 + quality-histogram bin, where
+// bin j <=> 6 + j <= mean_q < 7 + j <=> L * e(7 + j) < S <= L * e(6 + j).  The fp64 mean_q is within 1e-9 of the
+// exact value, so floor(mean_q - 6) is the bin or a neighbour of it: two or three exact comparisons settle it.
+__device__ __forceinline__ uint8_t quality_flags(uint64_t L, uint64_t H, uint64_t l32, const QThr& t, double* mq_out) {
+    const double S = (double)H * 4294967296.0 + (double)l32;
+    const double mq = -10.0 * log10(S / ((double)L * 4503599627370496.0));
+    *mq_out = mq;
+    const unsigned __int128 S128 = ((unsigned __int128)H << 32) + l32;
+    uint8_t fl = S128 > (unsigned __int128)L * t.fail ? 1 : 0;
+    int qbin = -1;
+    if (mq > 5.5 && mq < 14.5) {
+        int j = (int)floor(mq - 6.0);
+        j = j < 0 ? 0 : (j > PPQC_N_QHIST - 1 ? PPQC_N_QHIST - 1 : j);
+        const bool a = S128 <= (unsigned __int128)L * t.q[j];        // mean_q >= 6 + j
+        const bool b = S128 <= (unsigned __int128)L * t.q[j + 1];    // mean_q >= 7 + j
+        if (a && !b) qbin = j;
+        else if (!a) { if (j > 0 && S128 <= (unsigned __int128)L * t.q[j - 1]) qbin = j - 1; }
+        else if (j < PPQC_N_QHIST - 1 && !(S128 <= (unsigned __int128)L * t.q[j + 2])) qbin = j + 1;
+    }
+    return (uint8_t)(fl | ((qbin + 1) << 4));
 }
 
 // ---- byte classification shared by the per-read kernels and the FASTQ text kernels ------------------------------

@@ -191,27 +191,38 @@ __global__ __launch_bounds__(256) void chan_count_kernel(const uint32_t* __restr
 }
 
 // ---- pass 2: all SUM tables ------------------------------------------------------------------------------------------
+// Every block keeps private tables in LDS and leaves them, zeros included, in a slab of its own (plain coalesced stores);
+// tables_reduce_kernel adds the slabs up.  (Flushing the private tables with global atomics cost one memory-side atomic
+// per non-zero cell and block -- 2.4 * 10^6 of them at 3000 channels and 256 blocks, about 120 us at the chip's 20 per ns.)
 // Dynamic LDS layout (u64 first for alignment):
 //   u64 totals[16] | u64 hour_bases[nb] | u64 chan_bases[nchL] |
-//   u32 len_log2[40] | u32 len_lin[100] | u32 q[8] | u32 gc[20] | u32 hour_reads[nb] | u32 chan_reads[nchL] | u32 chan_fail[nchL]
+//   u32 len_log2[40 * kRep] | u32 len_lin[100 * kRep] | u32 q[8 * kRep] | u32 gc[20 * kRep] | u32 hour_reads[nb] |
+//   u32 chan_reads[nchL] | u32 chan_fail[nchL]
+// The four histograms have few, hot bins: kRep copies each (copy = lane mod kRep), so that the lanes of a wave that hit
+// one bin do not all queue on one LDS word.
 // nchL = n_channels when the per-channel accumulators fit in LDS, else 0 (then they go straight to global atomics).
 // cell_mode: 0 the cells are there already (every batch left them at submit time), 1 one packed atomic per read, 2 two.
-__global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf,
-                                                     const uint64_t* max_buf, uint32_t nchL, int cell_mode) {
+constexpr uint32_t kRep = 8;
+constexpr uint32_t kHistBins = PPQC_N_LEN_LOG2 + PPQC_N_LEN_LIN + PPQC_N_QHIST + PPQC_N_GCHIST;
+constexpr unsigned kTabThreads = 512, kTabMaxBlocks = 512;
+
+__global__ __launch_bounds__(kTabThreads) void tables_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf,
+                                                            const uint64_t* max_buf, uint32_t nchL, int cell_mode,
+                                                            uint64_t* __restrict__ slab) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t nb = tp.lay.n_time_bins, nch = tp.lay.n_channels, nmux = tp.lay.n_mux;
     unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(smem);
     unsigned long long* s_hbases = s_tot + PPQC_N_TOTALS;
     unsigned long long* s_cbases = s_hbases + nb;
     uint32_t* s_log2 = reinterpret_cast<uint32_t*>(s_cbases + nchL);
-    uint32_t* s_lin = s_log2 + PPQC_N_LEN_LOG2;
-    uint32_t* s_q = s_lin + PPQC_N_LEN_LIN;
-    uint32_t* s_gc = s_q + PPQC_N_QHIST;
-    uint32_t* s_hreads = s_gc + PPQC_N_GCHIST;
+    uint32_t* s_lin = s_log2 + PPQC_N_LEN_LOG2 * kRep;
+    uint32_t* s_q = s_lin + PPQC_N_LEN_LIN * kRep;
+    uint32_t* s_gc = s_q + PPQC_N_QHIST * kRep;
+    uint32_t* s_hreads = s_gc + PPQC_N_GCHIST * kRep;
     uint32_t* s_creads = s_hreads + nb;
     uint32_t* s_cfail = s_creads + nchL;
     const uint32_t n64 = PPQC_N_TOTALS + nb + nchL;
-    const uint32_t n32 = PPQC_N_LEN_LOG2 + PPQC_N_LEN_LIN + PPQC_N_QHIST + PPQC_N_GCHIST + nb + 2 * nchL;
+    const uint32_t n32 = kHistBins * kRep + nb + 2 * nchL;
     for (uint32_t k = threadIdx.x; k < n64; k += blockDim.x) s_tot[k] = 0;
     for (uint32_t k = threadIdx.x; k < n32; k += blockDim.x) s_log2[k] = 0;
     __syncthreads();
@@ -219,6 +230,7 @@ __global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n,
     unsigned long long* g = reinterpret_cast<unsigned long long*>(sum_buf);
     const uint64_t lin_w = max_buf[0] / PPQC_N_LEN_LIN + 1;
     const bool chan_lds = nchL != 0;
+    const uint32_t rep = threadIdx.x & (kRep - 1);
 
     uint64_t tot[PPQC_TOT_NO_TIME + 1] = {};   // thread-local run totals, added to LDS once at the end
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -230,6 +242,8 @@ __global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n,
         const uint32_t gc = ra.gc[i];
         const uint8_t fl = ra.flags[i];
         const uint32_t fail = fl & 1u;
+        const uint32_t m = ra.mux[i];
+        const int32_t h = ra.hour[i];
         tot[PPQC_TOT_N_BASES] += L;
         tot[PPQC_TOT_N_FAIL] += fail;
         tot[PPQC_TOT_N_GC] += gc;
@@ -237,40 +251,27 @@ __global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n,
         tot[PPQC_TOT_QSUM] += (uint64_t)ra.qsum[i];
         tot[PPQC_TOT_ZERO_LEN] += (L == 0);
         tot[PPQC_TOT_NO_TIME] += (ra.time[i] == INT64_MIN);
-        atomicAdd(&s_log2[L == 0 ? 0 : 32 - __clz(L)], 1u);
-        atomicAdd(&s_lin[L / lin_w], 1u);
-        // quality histogram: bin j <=> 6+j <= mean_q < 7+j <=> L*e(7+j) < S <= L*e(6+j)  (exact integers)
-        int qbin = -1;
-        if (fl & 2u) qbin = 0;   // flagged read: QScore 6.99
-        else if (fl & 4u) {      // pre-computed record: the reference only has the float, floor(q - 6) in fp64
-            const double q = ra.mean_q[i];
-            if (q >= 6.0 && q < 14.0) qbin = (int)floor(q - 6.0);
-        } else if (L != 0) {
-            const unsigned __int128 S = ((unsigned __int128)ra.err_hi[i] << 32) + ra.err_lo[i];
-#pragma unroll
-            for (int j = 0; j < PPQC_N_QHIST; ++j)
-                if (qbin < 0 && S <= (unsigned __int128)L * tp.thr_q[j] && S > (unsigned __int128)L * tp.thr_q[j + 1]) qbin = j;
-        }
-        if (qbin >= 0) atomicAdd(&s_q[qbin], 1u);
+        atomicAdd(&s_log2[(L == 0 ? 0 : 32 - __clz(L)) * kRep + rep], 1u);
+        atomicAdd(&s_lin[(uint32_t)(L / lin_w) * kRep + rep], 1u);
+        const uint32_t qb = fl >> 4;   // 1 + the bin of 6+j <= mean_q < 7+j, left by whoever computed mean_q (quality_flags)
+        if (qb) atomicAdd(&s_q[(qb - 1) * kRep + rep], 1u);
         if (gc > 0 && L != 0) {   // (a record may claim bases of an empty read: no bin, no division)
             uint32_t bin = (uint32_t)((20ull * gc) / L);
-            atomicAdd(&s_gc[bin > PPQC_N_GCHIST - 1 ? PPQC_N_GCHIST - 1 : bin], 1u);
+            atomicAdd(&s_gc[(bin > PPQC_N_GCHIST - 1 ? PPQC_N_GCHIST - 1 : bin) * kRep + rep], 1u);
         }
         if (chan_lds) { atomicAdd(&s_creads[c], 1u); atomicAdd(&s_cbases[c], (unsigned long long)L); }
         else { atomicAdd(&g[tp.lay.off_chan_reads + c], 1ull); atomicAdd(&g[tp.lay.off_chan_bases + c], (unsigned long long)L); }
-        const uint32_t m = ra.mux[i];
         if (m < 1 || m > nmux) { tot[PPQC_TOT_BAD_MUX] += 1; continue; }
         if (fail) {
             if (chan_lds) atomicAdd(&s_cfail[c], 1u);
             else atomicAdd(&g[tp.lay.off_chan_fail + c], 1ull);
         }
-        const int32_t h = ra.hour[i];
         if (h < 0 || h >= (int32_t)nb) { tot[PPQC_TOT_TIME_OOB] += 1; continue; }
         tot[PPQC_TOT_N_BINNED] += 1;
         atomicAdd(&s_hreads[h], 1u);
         atomicAdd(&s_hbases[h], (unsigned long long)L);
-        const uint64_t cell = ((uint64_t)c * nmux + (m - 1)) * nb + (uint32_t)h;
         if (cell_mode == 0) continue;
+        const uint64_t cell = ((uint64_t)c * nmux + (m - 1)) * nb + (uint32_t)h;
         if (cell_mode == 1) {   // one atomic per read: count in the bits above kCmhShift (cmh_unpack_kernel splits the cells)
             atomicAdd(&g[tp.lay.off_cmh_bases + cell], (1ull << kCmhShift) | (unsigned long long)L);
         } else {
@@ -282,26 +283,38 @@ __global__ __launch_bounds__(1024) void tables_kernel(ReadArrays ra, uint64_t n,
     for (int k = 0; k <= PPQC_TOT_NO_TIME; ++k)
         if (tot[k]) atomicAdd(&s_tot[k], (unsigned long long)tot[k]);
     __syncthreads();
-    // flush the non-zero privatised cells
-    for (uint32_t k = threadIdx.x; k < PPQC_N_TOTALS; k += blockDim.x)
-        if (s_tot[k]) atomicAdd(&g[tp.lay.off_totals + k], s_tot[k]);
-    for (uint32_t k = threadIdx.x; k < PPQC_N_LEN_LOG2; k += blockDim.x)
-        if (s_log2[k]) atomicAdd(&g[tp.lay.off_len_log2 + k], (unsigned long long)s_log2[k]);
-    for (uint32_t k = threadIdx.x; k < PPQC_N_LEN_LIN; k += blockDim.x)
-        if (s_lin[k]) atomicAdd(&g[tp.lay.off_len_lin + k], (unsigned long long)s_lin[k]);
-    for (uint32_t k = threadIdx.x; k < PPQC_N_QHIST; k += blockDim.x)
-        if (s_q[k]) atomicAdd(&g[tp.lay.off_q_hist + k], (unsigned long long)s_q[k]);
-    for (uint32_t k = threadIdx.x; k < PPQC_N_GCHIST; k += blockDim.x)
-        if (s_gc[k]) atomicAdd(&g[tp.lay.off_gc_hist + k], (unsigned long long)s_gc[k]);
+    // the block's tables into its slab, laid out like sum_buf[0, off_cmh_reads)
+    uint64_t* out = slab + (uint64_t)blockIdx.x * tp.lay.off_cmh_reads;
+    for (uint32_t k = threadIdx.x; k < PPQC_N_TOTALS; k += blockDim.x) out[tp.lay.off_totals + k] = s_tot[k];
+    for (uint32_t k = threadIdx.x; k < kHistBins; k += blockDim.x) {   // the four histograms lie back to back in both layouts
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < kRep; ++r) v += s_log2[k * kRep + r];
+        out[tp.lay.off_len_log2 + k] = v;
+    }
     for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) {
-        if (s_hreads[k]) atomicAdd(&g[tp.lay.off_hour_reads + k], (unsigned long long)s_hreads[k]);
-        if (s_hbases[k]) atomicAdd(&g[tp.lay.off_hour_bases + k], s_hbases[k]);
+        out[tp.lay.off_hour_reads + k] = s_hreads[k];
+        out[tp.lay.off_hour_bases + k] = s_hbases[k];
     }
-    for (uint32_t k = threadIdx.x; k < nchL; k += blockDim.x) {
-        if (s_creads[k]) atomicAdd(&g[tp.lay.off_chan_reads + k], (unsigned long long)s_creads[k]);
-        if (s_cbases[k]) atomicAdd(&g[tp.lay.off_chan_bases + k], s_cbases[k]);
-        if (s_cfail[k]) atomicAdd(&g[tp.lay.off_chan_fail + k], (unsigned long long)s_cfail[k]);
+    for (uint32_t k = threadIdx.x; k < nch; k += blockDim.x) {
+        out[tp.lay.off_chan_reads + k] = chan_lds ? s_creads[k] : 0u;
+        out[tp.lay.off_chan_bases + k] = chan_lds ? s_cbases[k] : 0ull;
+        out[tp.lay.off_chan_fail + k] = chan_lds ? s_cfail[k] : 0u;
     }
+}
+
+// sum_buf[k] += sum over the blocks' slabs, k < n_small: 64 words per block of 256 threads, four threads per word
+__global__ __launch_bounds__(256) void tables_reduce_kernel(const uint64_t* __restrict__ slab, uint32_t n_slabs,
+                                                            uint32_t n_small, uint64_t* sum_buf) {
+    __shared__ uint64_t part[4][64];
+    const uint32_t w = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const uint32_t k = blockIdx.x * 64 + w;
+    uint64_t v = 0;
+    if (k < n_small)
+        for (uint32_t b = q; b < n_slabs; b += 4) v += slab[(uint64_t)b * n_small + k];
+    part[q][w] = v;
+    __syncthreads();
+    if (q == 0 && k < n_small) sum_buf[k] += part[0][w] + part[1][w] + part[2][w] + part[3][w];
 }
 
 // ---- time_mode 1: reference hour-of-day + wrap quirk (lib/fast5_reader.py:117-126) ---------------------------------
@@ -383,7 +396,9 @@ __global__ __launch_bounds__(256) void records_kernel(ReadArrays ra, uint64_t ba
     const double q = mean_q[i];
     ra.len[g] = len[i]; ra.gc[g] = gc ? gc[i] : 0; ra.nn[g] = 0; ra.qsum[g] = 0; ra.mean_q[g] = q;
     ra.err_hi[g] = 0; ra.err_lo[g] = 0;
-    ra.flags[g] = (uint8_t)(4u | (q < fail_q ? 1u : 0u));   // float(q) < 7.00, lib/seq_routines.py:855
+    // float(q) < 7.00, lib/seq_routines.py:855; the reference only has the float, so the quality bin is floor(q - 6) in fp64
+    const uint32_t qbin1 = (q >= 6.0 && q < 14.0) ? 1u + (uint32_t)floor(q - 6.0) : 0u;
+    ra.flags[g] = (uint8_t)(4u | (q < fail_q ? 1u : 0u) | (qbin1 << 4));
     ra.channel[g] = channel[i]; ra.mux[g] = mux[i]; ra.time[g] = time[i];
 }
 hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const uint32_t* len, const double* mean_q,
@@ -489,25 +504,26 @@ hipError_t launch_cmh_unpack(const TableParams& tp, uint64_t* sum_buf, hipStream
     return hipGetLastError();
 }
 
+uint64_t tables_slab_words(const TableLayout& lay) { return (uint64_t)kTabMaxBlocks * lay.off_cmh_reads; }
+
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
-                         hipStream_t s, int cell_mode, const uint64_t* job_chan_count) {
+                         uint64_t* slab, hipStream_t s, int cell_mode, const uint64_t* job_chan_count) {
     if (n == 0) return hipSuccess;
     const uint32_t nb = tp.lay.n_time_bins;
-    // per-channel accumulators in LDS need 16 B per channel; keep the block under 64 KiB so 2 blocks fit a CU.  When
+    // per-channel accumulators in LDS need 16 B per channel; a block stays under 64 KiB, so two fit a CU.  When
     // channels and time bins together do not fit (3000 channels x 2048 bins), the per-channel accumulators go straight
-    // to global atomics (nchL = 0); the rest fits for every n_time_bins ppqc_create accepts (4096: 50 KiB).
-    auto lds_for = [nb](uint32_t k) {
-        return 8ull * (PPQC_N_TOTALS + nb + k) +
-               4ull * (PPQC_N_LEN_LOG2 + PPQC_N_LEN_LIN + PPQC_N_QHIST + PPQC_N_GCHIST + nb + 2ull * k);
-    };
+    // to global atomics (nchL = 0); the rest fits for every n_time_bins ppqc_create accepts (4096: 55 KiB).
+    auto lds_for = [nb](uint32_t k) { return 8ull * (PPQC_N_TOTALS + nb + k) + 4ull * (kHistBins * kRep + nb + 2ull * k); };
     uint32_t nchL = tp.lay.n_channels <= 3584 ? tp.lay.n_channels : 0;
     if (lds_for(nchL) > 64 * 1024) nchL = 0;
     const size_t lds = lds_for(nchL);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    // few, fat blocks: every block flushes its private tables once (measured on MI355X, config 2: 256 x 512 threads
-    // 0.317 ms for the whole finalize, 512 x 256: 0.34, 2048 x 256: 0.42)
-    hipLaunchKernelGGL(tables_kernel, dim3(grid_for(n, 256)),
-                       dim3(512), lds, s, ra, n, tp, sum_buf, max_buf, nchL, cell_mode);
+    // two blocks of 512 threads per CU (4 waves per SIMD): the kernel is bound by the latency of its eleven loads per read
+    const unsigned blocks = grid_for(n, kTabMaxBlocks);
+    hipLaunchKernelGGL(tables_kernel, dim3(blocks), dim3(kTabThreads), lds, s, ra, n, tp, sum_buf, max_buf, nchL, cell_mode,
+                       slab);
+    hipLaunchKernelGGL(tables_reduce_kernel, dim3((unsigned)((tp.lay.off_cmh_reads + 63) / 64)), dim3(256), 0, s, slab, blocks,
+                       (uint32_t)tp.lay.off_cmh_reads, sum_buf);
     if (cell_mode == 1) {
         const hipError_t e = launch_cmh_unpack(tp, sum_buf, s);
         if (e != hipSuccess) return e;

@@ -982,8 +982,8 @@ void tile_kernel_line_w(BatchView b, const uint64_t* __restrict__ lut_g, ReadArr
 // device words whose OR bounds every sort key, so that the sort + N50 chain can start right behind this kernel.
 __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadArrays ra, uint64_t read_base,
                                                              const Partial* __restrict__ head,
-                                                             const Partial* __restrict__ tail, uint64_t thr_fail,
-                                                             double fail_q, uint64_t* __restrict__ csr_errors,
+                                                             const Partial* __restrict__ tail, QThr thr,
+                                                             uint64_t* __restrict__ csr_errors,
                                                              uint32_t n_channels, uint64_t* __restrict__ gate,
                                                              int write_lens) {
     __shared__ uint32_t s_max;
@@ -1013,18 +1013,12 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
         uint32_t len_out = 0;
         if (flagged) {
             // lib/fast5_reader.py:37-40: a 'fail' path keeps ReadLength = 0, QScore = 6.99, GCcont = 0
-            flags = 2 | (6.99 < fail_q ? 1 : 0);
+            flags = 2 | (6.99 < thr.fail_q ? 1 : 0) | (1 << 4);   // QScore 6.99: quality bin 0
             ra.len[g] = 0; ra.gc[g] = 0; ra.nn[g] = 0; ra.qsum[g] = 0; ra.err_hi[g] = 0; ra.err_lo[g] = 0;
             mq = 6.99;
         } else {
-            if (L != 0) {
-                const double S = (double)H * 4294967296.0 + (double)l32;
-                mq = -10.0 * log10(S / ((double)L * 4503599627370496.0));
-                const unsigned __int128 S128 = ((unsigned __int128)H << 32) + l32;
-                flags = S128 > (unsigned __int128)L * thr_fail ? 1 : 0;
-            } else {
-                flags = 0.0 < fail_q ? 1 : 0;
-            }
+            if (L != 0) flags = quality_flags(L, H, l32, thr, &mq);
+            else flags = 0.0 < thr.fail_q ? 1 : 0;
             len_out = (uint32_t)L;
             ra.len[g] = (uint32_t)L; ra.gc[g] = (uint32_t)gcs; ra.nn[g] = (uint32_t)nn;
             ra.qsum[g] = (int64_t)qb - 33 * (int64_t)L;
@@ -1129,12 +1123,12 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
 uint64_t dense_list_words(uint64_t n_tiles) { return kDenseHeader + kDenseSubs * dense_sub_cap(n_tiles); }
 
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
-                                 const Partial* tail, uint64_t thr_fail, double fail_q, uint64_t* csr_errors,
+                                 const Partial* tail, const QThr& thr, uint64_t* csr_errors,
                                  uint32_t n_channels, uint64_t* gate, bool write_lens, hipStream_t s) {
     if (b.n_reads == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((b.n_reads + 255) / 256);
-    hipLaunchKernelGGL(finalize_reads_kernel, dim3(blocks), dim3(256), 0, s, b, ra, read_base, head, tail, thr_fail,
-                       fail_q, csr_errors, n_channels, gate, write_lens ? 1 : 0);
+    hipLaunchKernelGGL(finalize_reads_kernel, dim3(blocks), dim3(256), 0, s, b, ra, read_base, head, tail, thr,
+                       csr_errors, n_channels, gate, write_lens ? 1 : 0);
     return hipGetLastError();
 }
 
