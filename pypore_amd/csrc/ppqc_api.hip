@@ -121,6 +121,7 @@ struct ppqc_ctx {
     bool res_busy = false;   // a finalize phase (or a caller's collective on the tables) may still run: set by every
                              // finalize phase, cleared when the stream has been synchronised
     hipEvent_t last_a = nullptr, sort_end = nullptr;   // start event of the newest batch (submit_ms_last)
+    hipEvent_t last_b = nullptr;   // behind the newest batch's per-read kernel(s), in front of its finalize_reads
     uint64_t* lut_dev = nullptr;
 
     ReadArrays ra{};
@@ -559,6 +560,7 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     c->last_a = ev.a;
     HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->dense, c->tn, s));
     HIPCHK(hipEventRecord(ev.b, s));
+    c->last_b = ev.b;
     c->pending.push_back(ev);
     const bool pre = c->pre_ok && c->res_clean && c->cfg.time_mode == 0 && c->tn.pre != 0;
     if (!pre) c->pre_ok = false;
@@ -577,7 +579,8 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
         HIPCHK(hipStreamWaitEvent(c->aux, ev.a, 0));
         HIPCHK(launch_batch_extremes(v, base, c->ra, c->tp, c->max_buf, c->min_buf, c->tminmax,
                                      c->res_buf + c->res_words + 4, c->maxlen_host + 4,
-                                     cells ? c->sum_buf + c->tp.lay.off_cmh_bases : nullptr, c->aux));
+                                     cells ? c->sum_buf + c->tp.lay.off_cmh_bases : nullptr,
+                                     c->res_buf + c->res_words + 8, c->aux));
         if (cells) c->cells_dirty = true;
         HIPCHK(hipEventRecord(c->ev_pre, c->aux));
         HIPCHK(hipStreamWaitEvent(s, c->ev_pre, 0));
@@ -1114,9 +1117,11 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     // of finalize_reads: run beside the tile kernel its ten launches cost that kernel more time (3 %: every wave
     // resident beside it displaces one of its own) than they take behind it, beside the tables kernel.
     const bool pre = local && c->pre_run && ss != s;
-    if (ss != s) HIPCHK(hipStreamWaitEvent(ss, early ? c->ev_reads : c->ev_max, 0));
+    // pre: the keys come from the batches' index kernels, so the chain does not wait for finalize_reads either: it starts
+    // when the per-read kernel ends and runs beside finalize_reads and the tables
+    if (ss != s) HIPCHK(hipStreamWaitEvent(ss, pre && c->last_b ? c->last_b : (early ? c->ev_reads : c->ev_max), 0));
     c->sort_start = c->ev_s0;
-    if (ss != s && early && c->n_reads) c->sort_start = c->ev_reads;   // the chain starts right behind it
+    if (ss != s && early && c->n_reads && !(pre && c->last_b)) c->sort_start = c->ev_reads;   // the chain starts right behind it
     else HIPCHK(hipEventRecord(c->ev_s0, ss));
     // The N50 word of the mirror lies outside the copied range (the spare word behind the error words), so the copy,
     // which carries the device's not yet final n50_out along, cannot overwrite it.

@@ -120,7 +120,7 @@ hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uin
                            int64_t* tminmax, bool write_lens, hipStream_t s);
 hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays ra, const TableParams& tp,
                                  uint64_t* max_buf, uint64_t* min_buf, int64_t* tminmax, uint64_t* bound,
-                                 uint64_t* bound_host, uint64_t* cells, hipStream_t s);   // at submit time, beside the tile
+                                 uint64_t* bound_host, uint64_t* cells, uint64_t* gate, hipStream_t s);   // at submit time, beside the tile
                                  // kernel; cells != nullptr: the batch's packed (channel, mux, hour) cells too (cmh_bases region)
 // (channel, mux, hour) cells: one packed atomic per read when the run's reads and bases (host-known) fit the two fields
 bool cmh_packable(uint64_t n_reads, uint64_t n_bases);

@@ -39,7 +39,8 @@ template <bool BATCH>
 __global__ __launch_bounds__(1024) void extremes_kernel(BatchView b, uint64_t base, ReadArrays ra, uint64_t n,
                                                        TableParams tp, uint64_t* max_buf, uint64_t* min_buf,
                                                        int64_t* tminmax, uint32_t nchL, int write_lens, uint64_t* bound,
-                                                       uint64_t* __restrict__ bound_host, uint64_t* cells) {
+                                                       uint64_t* __restrict__ bound_host, uint64_t* cells,
+                                                       uint64_t* gate) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* s_cmax = reinterpret_cast<uint32_t*>(smem);
     uint32_t* s_cmin = s_cmax + nchL;
@@ -93,8 +94,12 @@ __global__ __launch_bounds__(1024) void extremes_kernel(BatchView b, uint64_t ba
             }
         }
         if (tp.time_mode == 0) ra.hour[g] = hour;
+        uint32_t m = 0;
+        if (BATCH) {   // the batch's metadata into the run's arrays (finalize_reads leaves them to this kernel)
+            m = b.mux[i];
+            ra.channel[g] = ch; ra.mux[g] = (uint8_t)m; ra.time[g] = t;
+        }
         if (BATCH && cells != nullptr && hour >= 0) {   // hour >= 0: channel and start time are good, time_mode is 0
-            const uint32_t m = b.mux[i];
             if (m >= 1 && m <= tp.lay.n_mux)
                 atomicAdd((unsigned long long*)&cells[((uint64_t)(ch - 1) * tp.lay.n_mux + (m - 1)) * tp.lay.n_time_bins + (uint32_t)hour],
                           (1ull << kCmhShift) | (unsigned long long)L);
@@ -116,6 +121,8 @@ __global__ __launch_bounds__(1024) void extremes_kernel(BatchView b, uint64_t ba
         atomicMin((long long*)&tminmax[0], s_tmin);
         atomicMax((long long*)&tminmax[1], s_tmax);
         if (BATCH) {
+            // the sort gate (words whose OR bounds every sort key of the run: finalize_reads_kernel raises it otherwise)
+            if (s_max) atomicOr((unsigned long long*)&gate[blockIdx.x & (kGateWords - 1)], s_max);
             __threadfence();
             const unsigned long long ticket = atomicAdd((unsigned long long*)&bound[1], 1ull);
             if (ticket == gridDim.x - 1ull) {
@@ -303,18 +310,32 @@ __global__ __launch_bounds__(kTabThreads) void tables_kernel(ReadArrays ra, uint
     }
 }
 
-// sum_buf[k] += sum over the blocks' slabs, k < n_small: 64 words per block of 256 threads, four threads per word
+// sum_buf[k] += sum over the blocks' slabs, k < n_small: 16 words per block of 256 threads, sixteen threads per word with
+// four loads in flight each (the kernel is nothing but the latency of its loads)
 __global__ __launch_bounds__(256) void tables_reduce_kernel(const uint64_t* __restrict__ slab, uint32_t n_slabs,
                                                             uint32_t n_small, uint64_t* sum_buf) {
-    __shared__ uint64_t part[4][64];
-    const uint32_t w = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const uint32_t k = blockIdx.x * 64 + w;
-    uint64_t v = 0;
-    if (k < n_small)
-        for (uint32_t b = q; b < n_slabs; b += 4) v += slab[(uint64_t)b * n_small + k];
-    part[q][w] = v;
+    __shared__ uint64_t part[16][16];
+    const uint32_t w = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const uint32_t k = blockIdx.x * 16 + w;
+    uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    if (k < n_small) {
+        uint32_t b = q;
+        for (; b + 48 < n_slabs; b += 64) {
+            v0 += slab[(uint64_t)b * n_small + k];
+            v1 += slab[(uint64_t)(b + 16) * n_small + k];
+            v2 += slab[(uint64_t)(b + 32) * n_small + k];
+            v3 += slab[(uint64_t)(b + 48) * n_small + k];
+        }
+        for (; b < n_slabs; b += 16) v0 += slab[(uint64_t)b * n_small + k];
+    }
+    part[q][w] = v0 + v1 + v2 + v3;
     __syncthreads();
-    if (q == 0 && k < n_small) sum_buf[k] += part[0][w] + part[1][w] + part[2][w] + part[3][w];
+    if (q == 0 && k < n_small) {
+        uint64_t t = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += part[j][w];
+        sum_buf[k] += t;
+    }
 }
 
 // ---- time_mode 1: reference hour-of-day + wrap quirk (lib/fast5_reader.py:117-126) ---------------------------------
@@ -452,14 +473,14 @@ hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uin
     hipLaunchKernelGGL(extremes_kernel<false>, dim3(grid_for(n, 256)),
                        dim3(512), (size_t)nchL * 8, s, BatchView{}, (uint64_t)0, ra, n, tp,
                        max_buf, min_buf, tminmax, nchL, write_lens ? 1 : 0, (uint64_t*)nullptr, (uint64_t*)nullptr,
-                       (uint64_t*)nullptr);
+                       (uint64_t*)nullptr, (uint64_t*)nullptr);
     return hipGetLastError();
 }
 
 // The same for one batch at submit time (see extremes_kernel<true>); bound[1] must be zero between launches.
 hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays ra, const TableParams& tp,
                                  uint64_t* max_buf, uint64_t* min_buf, int64_t* tminmax, uint64_t* bound,
-                                 uint64_t* bound_host, uint64_t* cells, hipStream_t s) {
+                                 uint64_t* bound_host, uint64_t* cells, uint64_t* gate, hipStream_t s) {
     if (b.n_reads == 0) return hipSuccess;
     const uint32_t nchL = tp.lay.n_channels <= kExtremesLdsChannels ? tp.lay.n_channels : 0;
     // A small grid on purpose: the tile kernel fills every SIMD's registers (4 waves of 128), so each wave resident
@@ -468,7 +489,7 @@ hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays r
     // nothing (2048 waves of 8 reads each cost config 2 about 15 us of tile-kernel time).
     hipLaunchKernelGGL(extremes_kernel<true>, dim3(grid_for(b.n_reads, 64)),
                        dim3(256), (size_t)nchL * 8, s, b, base, ra, b.n_reads, tp, max_buf,
-                       min_buf, tminmax, nchL, 1, bound, bound_host, cells);
+                       min_buf, tminmax, nchL, 1, bound, bound_host, cells, gate);
     return hipGetLastError();
 }
 
@@ -522,7 +543,7 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
     const unsigned blocks = grid_for(n, kTabMaxBlocks);
     hipLaunchKernelGGL(tables_kernel, dim3(blocks), dim3(kTabThreads), lds, s, ra, n, tp, sum_buf, max_buf, nchL, cell_mode,
                        slab);
-    hipLaunchKernelGGL(tables_reduce_kernel, dim3((unsigned)((tp.lay.off_cmh_reads + 63) / 64)), dim3(256), 0, s, slab, blocks,
+    hipLaunchKernelGGL(tables_reduce_kernel, dim3((unsigned)((tp.lay.off_cmh_reads + 15) / 16)), dim3(256), 0, s, slab, blocks,
                        (uint32_t)tp.lay.off_cmh_reads, sum_buf);
     if (cell_mode == 1) {
         const hipError_t e = launch_cmh_unpack(tp, sum_buf, s);

@@ -978,8 +978,10 @@ void tile_kernel_line_w(BatchView b, const uint64_t* __restrict__ lut_g, ReadArr
 }
 
 // One thread per read: merge the partials of reads that span tiles, define empty reads, then decode the raw sums.
-// Also leaves the sort input of the run (lens32: the length, 0 for reads without a valid channel) and raises `gate`, the
-// device words whose OR bounds every sort key, so that the sort + N50 chain can start right behind this kernel.
+// write_lens: also copies the batch's channel / mux / start time into the run's arrays, leaves the sort input of the run
+// (lens32: the length, 0 for reads without a valid channel) and raises `gate`, the device words whose OR bounds every sort
+// key, so that the sort + N50 chain can start right behind this kernel -- unless the batch's index kernel has done all
+// that beside the per-read kernel (extremes_kernel<true>; the host then knows the largest key).
 __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadArrays ra, uint64_t read_base,
                                                              const Partial* __restrict__ head,
                                                              const Partial* __restrict__ tail, QThr thr,
@@ -1024,15 +1026,17 @@ __global__ __launch_bounds__(256) void finalize_reads_kernel(BatchView b, ReadAr
             ra.qsum[g] = (int64_t)qb - 33 * (int64_t)L;
             ra.err_hi[g] = H; ra.err_lo[g] = l32;
         }
-        const uint32_t ch = b.channel[i];
-        const uint32_t key = (ch >= 1 && ch <= n_channels) ? len_out : 0u;   // what extremes_kernel would write
-        if (write_lens) ra.lens32[g] = key;   // else the batch's extremes kernel wrote it at submit time
-        if (key) atomicMax(&s_max, key);
         ra.mean_q[g] = mq;
         ra.flags[g] = flags;
-        ra.channel[g] = ch;
-        ra.mux[g] = b.mux[i];
-        ra.time[g] = b.time[i];
+        if (write_lens) {   // else the batch's index kernel did all of this at submit time (extremes_kernel<true>)
+            const uint32_t ch = b.channel[i];
+            const uint32_t key = (ch >= 1 && ch <= n_channels) ? len_out : 0u;   // what extremes_kernel would write
+            ra.lens32[g] = key;
+            if (key) atomicMax(&s_max, key);
+            ra.channel[g] = ch;
+            ra.mux[g] = b.mux[i];
+            ra.time[g] = b.time[i];
+        }
     }
     __syncthreads();
     // 64 gate words, picked by block: thousands of atomics on ONE address would serialise (measured: +40 us)
