@@ -122,6 +122,7 @@ struct ppqc_ctx {
                              // finalize phase, cleared when the stream has been synchronised
     hipEvent_t last_a = nullptr, sort_end = nullptr;   // start event of the newest batch (submit_ms_last)
     hipEvent_t last_b = nullptr;   // behind the newest batch's per-read kernel(s), in front of its finalize_reads
+    bool last_dense_alone = false; // ... which was dense_kernel alone (a batch of short reads)
     uint64_t* lut_dev = nullptr;
 
     ReadArrays ra{};
@@ -558,7 +559,8 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     HIPCHK(hipEventRecord(ev.a, s));
     hipEvent_t prev_a = c->last_a;
     c->last_a = ev.a;
-    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->dense, c->tn, s));
+    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->dense, c->tn, s, false,
+                              &c->last_dense_alone));
     HIPCHK(hipEventRecord(ev.b, s));
     c->last_b = ev.b;
     c->pending.push_back(ev);
@@ -1119,7 +1121,11 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     const bool pre = local && c->pre_run && ss != s;
     // pre: the keys come from the batches' index kernels, so the chain does not wait for finalize_reads either: it starts
     // when the per-read kernel ends and runs beside finalize_reads and the tables
-    if (ss != s) HIPCHK(hipStreamWaitEvent(ss, pre && c->last_b ? c->last_b : (early ? c->ev_reads : c->ev_max), 0));
+    // ... and beside the per-read kernel itself, right behind the index kernels, when that kernel is dense_kernel alone:
+    // it is bound by its instruction issue at three waves per SIMD and leaves registers and bandwidth for the chain's
+    // waves, which tile_kernel (four waves of 128 registers, the HBM saturated) does not (measured: 100 us lost for 60 won).
+    const bool beside = pre && (c->tn.sort_beside >= 0 ? c->tn.sort_beside != 0 : c->last_dense_alone);
+    if (ss != s) HIPCHK(hipStreamWaitEvent(ss, beside ? c->ev_pre : (pre && c->last_b ? c->last_b : (early ? c->ev_reads : c->ev_max)), 0));
     c->sort_start = c->ev_s0;
     if (ss != s && early && c->n_reads && !(pre && c->last_b)) c->sort_start = c->ev_reads;   // the chain starts right behind it
     else HIPCHK(hipEventRecord(c->ev_s0, ss));
@@ -1394,7 +1400,7 @@ int ppqc_set_tuning(ppqc_ctx* c, const char* name, int value) {
         {"tile_dense", &c->tn.tile_dense, -1, 1},       {"dense_len", &c->tn.dense_len, -1, 1 << 16},
         {"tile_all", &c->tn.tile_all, -1, 1},           {"tile_shift", &c->tn.tile_shift, -1, kMaxTileShift},
         {"pre", &c->tn.pre, -1, 1},                     {"fastq_sums", &c->tn.fastq_sums, -1, 2},
-        {"fastq_hdr_aux", &c->tn.fastq_hdr_aux, -1, 2},
+        {"fastq_hdr_aux", &c->tn.fastq_hdr_aux, -1, 2}, {"sort_beside", &c->tn.sort_beside, -1, 1},
     };
     for (auto& k : knobs)
         if (strcmp(name, k.n) == 0) {

@@ -102,11 +102,13 @@ struct Tuning {
     int tile_shift = -1;    // log2 of the tile size (12 .. 16); -1: by the batch's size
     int pre = -1;           // 0: no index kernel at submit time (extremes at finalize time); -1 / 1: whenever possible
     int fastq_sums = -1;    // FASTQ text: 0 line-mode second pass, 2 span sums of the scan pass, -1 / 1 by the last text's lines
+    int sort_beside = -1;   // 1: the sort + N50 chain starts behind the batches' index kernels, beside the per-read kernel; 0: at
+                            // that kernel's end; -1: beside it when it is dense_kernel alone (ppqc_finalize_n50)
     int fastq_hdr_aux = -1; // FASTQ text: 0 header kernel in front of the line pass, 2 beside it, -1 / 1 beside line_sum only
 };
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
                               Partial* head, Partial* tail, DenseList& dl, const Tuning& tn, hipStream_t s,
-                              bool line_mode = false);
+                              bool line_mode = false, bool* dense_alone = nullptr);   // *dense_alone: dense_kernel took every tile
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, const QThr& thr, uint64_t* csr_errors,
                                  uint32_t n_channels, uint64_t* gate, bool write_lens, hipStream_t s);

@@ -220,6 +220,8 @@ hipError_t sort_u64_pairs(uint64_t* keys, uint64_t* tmp_keys, uint32_t* vals, ui
 // suffix(i) = sum_{j >= i} s[j];  N50 = s[i*] for the largest i* with 2 * suffix(i*) >= total.
 constexpr int kN50Items = 8;
 constexpr int kN50Block = 256 * kN50Items;
+constexpr int kN50Groups = 8;   // key blocks per workgroup: one ticket (a device-scope atomic on ONE word, about 90 per us
+                                // for the whole chip) per 16 384 keys instead of per 2048
 
 uint64_t n50_block_words(uint64_t n) { return (n + kN50Block - 1) / kN50Block + 2; }   // [0] ticket counter, then the sums
 
@@ -233,7 +235,7 @@ __device__ __forceinline__ const uint32_t* gated_pick(const uint32_t* a, const u
     return (top & 1) ? b : a;
 }
 
-// One kernel.  Every block writes the sum of its 2048 keys and takes a ticket; the block that draws the last ticket has
+// One kernel.  Every workgroup writes the sums of its kN50Groups blocks of 2048 keys and takes a ticket; the block that draws the last ticket has
 // all sums behind its fence, scans them from the top (256 threads, a segment each), finds the block the N50 lies in and
 // searches that block's keys.  ws[0] is the ticket counter (zero between launches: the last block puts it back),
 // ws[1 + b] the sum of block b.  `host_out` (may be null): a pinned host word that receives the N50 as well, so that a
@@ -249,10 +251,10 @@ __global__ __launch_bounds__(256) void n50_kernel(const uint32_t* __restrict__ s
     __shared__ uint64_t s_total, s_after;
     __shared__ uint32_t s_blk, s_last;
     const uint32_t t = threadIdx.x;
-    if (t == 0) acc = 0;
-    __syncthreads();
-    {
-        const uint64_t b0 = (uint64_t)blockIdx.x * kN50Block;
+    for (uint32_t kb = blockIdx.x * kN50Groups; kb < (blockIdx.x + 1) * kN50Groups && kb < nblocks; ++kb) {
+        if (t == 0) acc = 0;
+        __syncthreads();
+        const uint64_t b0 = (uint64_t)kb * kN50Block;
         uint32_t v[kN50Items];
 #pragma unroll
         for (int k = 0; k < kN50Items; ++k) {
@@ -264,13 +266,14 @@ __global__ __launch_bounds__(256) void n50_kernel(const uint32_t* __restrict__ s
         for (int k = 0; k < kN50Items; ++k) sum += v[k];
         sum = wave_sum_u64(sum);
         if ((t & 63) == 0) atomicAdd(&acc, (unsigned long long)sum);
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(&ws[1 + kb], (uint64_t)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
     }
-    __syncthreads();
     if (t == 0) {
-        __hip_atomic_store(&ws[1 + blockIdx.x], (uint64_t)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
         const unsigned long long ticket = atomicAdd((unsigned long long*)&ws[0], 1ull);
-        s_last = ticket == (unsigned long long)nblocks - 1ull;
+        s_last = ticket == (unsigned long long)gridDim.x - 1ull;
     }
     __syncthreads();
     if (!s_last) return;
@@ -341,7 +344,7 @@ static hipError_t n50_launch(const uint32_t* sa, const uint32_t* sb, const uint6
         return hipMemsetAsync(out, 0, 16, s);
     }
     const uint64_t nblocks = (n + kN50Block - 1) / kN50Block;
-    hipLaunchKernelGGL(n50_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, sa, sb, gate, gate_words, in, n, block_sums,
+    hipLaunchKernelGGL(n50_kernel, dim3((unsigned)((nblocks + kN50Groups - 1) / kN50Groups)), dim3(256), 0, s, sa, sb, gate, gate_words, in, n, block_sums,
                        (uint32_t)nblocks, out, host_out);
     return hipGetLastError();
 }

@@ -1060,7 +1060,8 @@ constexpr uint64_t kSmallBatchBytes = 256ull << 20;
 // force either kernel on every tile and move the thresholds: the results are the same, the tests hold them to each other.
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
                               Partial* head, Partial* tail, DenseList& dl, const Tuning& tn, hipStream_t s,
-                              bool line_mode) {
+                              bool line_mode, bool* dense_alone) {
+    if (dense_alone) *dense_alone = false;
     if (b.n_bytes == 0 || b.n_reads == 0) return hipSuccess;
     uint32_t mode = tn.tile_dense < 0 ? 0u : (tn.tile_dense ? 2u : 1u);   // 0 probe every tile, 1 none dense, 2 all dense
     if (!dl.base) mode = 1;
@@ -1074,6 +1075,7 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
                          ? tn.tile_all != 0
                          : (mode == 0 && b.n_bytes / b.n_reads < (b.n_bytes < kSmallBatchBytes ? kDenseAllLenSmall : kDenseAllLen));
     if (all) {
+        if (dense_alone) *dense_alone = true;
         uint64_t blocks = (n_tiles + 3) / 4;
         if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
         if (line_mode)
