@@ -130,7 +130,8 @@ struct ppqc_ctx {
 
     Partial *head = nullptr, *tail = nullptr;
     uint64_t cap_tiles = 0;
-    DenseList dense{nullptr, 0};   // [2 counters, 6 spare | entries]: tiles the per-read kernel leaves to dense_kernel
+    DenseList dense{nullptr, 0};   // [2 x 64 counters | entries]: tiles the per-read kernel leaves to dense_kernel
+    DenseList slow{nullptr, 0};    // same layout: tiles dense_kernel leaves to its SLOW instantiation
 
     Slot slot[2];
 
@@ -244,6 +245,9 @@ static int ensure_tiles(ppqc_ctx* c, uint64_t n_tiles) {
     CHK(grow(&c->dense.base, 0, dense_list_words(cap), c->stream));
     HIPCHK(hipMemsetAsync(c->dense.base, 0, 128 * 8, c->stream));   // all counters; every launch leaves the next one's at zero
     c->dense.parity = 0;
+    CHK(grow(&c->slow.base, 0, dense_list_words(cap), c->stream));
+    HIPCHK(hipMemsetAsync(c->slow.base, 0, 128 * 8, c->stream));
+    c->slow.parity = 0;
     c->cap_tiles = cap;
     return PPQC_OK;
 }
@@ -375,7 +379,13 @@ static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_hdr, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_cells, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_cmhcopy, hipEventDisableTiming));
-    HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    {   // The auxiliary stream's kernels are few and small and run BESIDE the per-read kernel, whose grid of tens of thousands
+        // of workgroups otherwise keeps every wave slot it frees for itself (dense_kernel: four waves of 128 registers per
+        // SIMD): at the highest priority the dispatcher places their workgroups first whenever a slot opens.
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, greatest));
+    }
     HIPCHK(hipEventCreate(&c->ev_join));
     HIPCHK(hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->ev_reads));
@@ -468,7 +478,7 @@ int ppqc_destroy(ppqc_ctx* c) {
     ReadArrays& r = c->ra;
     void* ptrs[] = {r.rec_cnt, r.rec_hi, r.rec_lo, r.len, r.gc, r.nn, r.qsum, r.mean_q, r.err_hi, r.err_lo, r.flags,
                     r.channel, r.mux, r.time, r.hour, r.lens32, c->head, c->tail, c->res_buf, c->sk32, c->sk32_tmp, c->counts, c->vals, c->vals_tmp, c->sk64,
-                    c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev, c->dense.base, c->fq.counts, c->fq.n_entries, c->fq.entries, c->fq.prefix,
+                    c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev, c->dense.base, c->slow.base, c->fq.counts, c->fq.n_entries, c->fq.entries, c->fq.prefix,
                     c->fq.block_sums, c->fq.line_off, c->fq.span_sum, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo, c->m1, c->cc, c->tab_slab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->res_host) (void)hipHostFree(c->res_host);
@@ -559,7 +569,7 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     HIPCHK(hipEventRecord(ev.a, s));
     hipEvent_t prev_a = c->last_a;
     c->last_a = ev.a;
-    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->dense, c->tn, s, false,
+    HIPCHK(launch_tile_kernel(v, c->lut_dev, c->ra, base, c->head, c->tail, c->dense, c->slow, c->tn, s, false,
                               &c->last_dense_alone));
     HIPCHK(hipEventRecord(ev.b, s));
     c->last_b = ev.b;
@@ -742,7 +752,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     } else {
         // line mode: both classifiers run over the same text, every line is a segment
         BatchView v{text, text, c->fq.line_off, n_lines, n, nullptr, shift, nullptr, nullptr, nullptr};
-        HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->dense, c->tn, s, true));
+        HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->dense, c->slow, c->tn, s, true));
     }
     if (hdr_aux) HIPCHK(hipStreamWaitEvent(s, c->ev_hdr, 0));
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,

@@ -107,7 +107,7 @@ struct Tuning {
     int fastq_hdr_aux = -1; // FASTQ text: 0 header kernel in front of the line pass, 2 beside it, -1 / 1 beside line_sum only
 };
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
-                              Partial* head, Partial* tail, DenseList& dl, const Tuning& tn, hipStream_t s,
+                              Partial* head, Partial* tail, DenseList& dl, DenseList& slow, const Tuning& tn, hipStream_t s,
                               bool line_mode = false, bool* dense_alone = nullptr);   // *dense_alone: dense_kernel took every tile
 hipError_t launch_finalize_reads(const BatchView& b, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, const QThr& thr, uint64_t* csr_errors,

@@ -487,7 +487,11 @@ hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays r
     // beside it displaces one of its waves for as long as it lives, and under a saturated HBM a latency-bound wave lives
     // long.  64 x 256 threads finish well inside the tile kernel of any batch worth the trouble and cost it next to
     // nothing (2048 waves of 8 reads each cost config 2 about 15 us of tile-kernel time).
-    hipLaunchKernelGGL(extremes_kernel<true>, dim3(grid_for(b.n_reads, 64)),
+    // ... while a batch of many short reads needs a wider grid, or this kernel outlasts the per-read kernel (8 * 10^6 reads of
+    // 150 bases: 1.4 ms on 64 workgroups beside 0.7 ms of dense_kernel): 16 384 reads per workgroup, 64 to 512 workgroups.
+    uint64_t wg = b.n_reads / 16384;
+    wg = wg < 64 ? 64 : (wg > 512 ? 512 : wg);
+    hipLaunchKernelGGL(extremes_kernel<true>, dim3(grid_for(b.n_reads, (unsigned)wg)),
                        dim3(256), (size_t)nchL * 8, s, b, base, ra, b.n_reads, tp, max_buf,
                        min_buf, tminmax, nchL, 1, bound, bound_host, cells, gate);
     return hipGetLastError();

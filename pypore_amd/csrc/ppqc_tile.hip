@@ -642,7 +642,13 @@ __device__ __forceinline__ void span_scan(const uint4& vb, const uint4& vq, uint
     }
 }
 
-constexpr int kDenseSpans = 4;   // spans per batch of a dense tile (32 VGPRs of data; the boundary pass needs the rest)
+#ifndef PPQC_DENSE_SPANS
+#define PPQC_DENSE_SPANS 4
+#endif
+#ifndef PPQC_DENSE_OCC
+#define PPQC_DENSE_OCC 4
+#endif
+constexpr int kDenseSpans = PPQC_DENSE_SPANS;   // spans per batch of a dense tile (32 VGPRs of data; the boundary pass needs the rest)
 
 // Two registers of upcoming read ends: w0 lane l = offsets[r0 + 1 + l], w1 lane l = offsets[r0 + 65 + l] (clamped to
 // offsets[R]).  Any 64 consecutive reads from r on, r - r0 < 64, are then at hand without a load; when r passes r0 + 64
@@ -706,11 +712,17 @@ constexpr int kQN = 128;   // ring slots per wave: a span adds at most 63 entrie
 
 struct PreSums { uint32_t gcs, n, qb; uint64_t err; };
 
-template <bool LINE, bool ALL>
-__global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra,
-                                                        uint64_t read_base, Partial* __restrict__ head,
-                                                        Partial* __restrict__ tail, uint64_t* __restrict__ base,
-                                                        int parity) {
+// SLOW.  A span in which 64 or more reads end (reads of fewer than 16 bytes on average) needs span_scan, whose registers
+// would cost the kernel a wave per SIMD although hardly any input ever takes it (152 instead of 122 VGPRs).  So the
+// kernel proper (SLOW = false, four waves per SIMD) does not contain it: a wave that meets such a span -- or a malformed
+// index -- appends its tile to a second list, `slow`, of the same layout and goes on with the next tile, and the SLOW
+// instantiation (three waves per SIMD, list-driven, launched behind it) does those tiles from their start; whatever
+// the first wave had stored for the tile is stored again, with the same values.
+template <bool LINE, bool ALL, bool SLOW>
+__global__ __launch_bounds__(256, (SLOW ? 3 : PPQC_DENSE_OCC))
+void dense_kernel(BatchView b, const uint64_t* __restrict__ lut_g, ReadArrays ra, uint64_t read_base,
+                  Partial* __restrict__ head, Partial* __restrict__ tail, uint64_t* __restrict__ base, int parity,
+                  DenseOut slow) {
     constexpr int ND = kDenseSpans;
     __shared__ uint64_t lut[256];
     __shared__ uint32_t xs[4][64];
@@ -766,6 +778,8 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
         load_batch<ND, LINE>(vb, vq, pb, pq, 0, c.lane_off, last_vec);
         Walk w;
         w.r = ALL ? find_read(c.off, c.R, tile_start, lane) : e >> 32;
+        const uint64_t r_first = w.r;
+        bool hard = false;   // !SLOW: the tile has been left to the SLOW instantiation
         w.rs = uniform_u64(c.off[w.r]);
         w.done = false;
         w.win = 0; w.win_r0 = 0; w.win_ok = false;
@@ -821,11 +835,11 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
             Pp = PreSums{0, 0, 0, 0};
         };
 
-        for (uint32_t s0 = 0; s0 < n_spans && !w.done; s0 += ND) {
+        for (uint32_t s0 = 0; s0 < n_spans && !w.done && !hard; s0 += ND) {
             if (s0) load_batch<ND, LINE>(vb, vq, pb, pq, s0, c.lane_off, last_vec);
 #pragma unroll
             for (int k = 0; k < ND; ++k) {
-                if (s0 + k >= n_spans || w.done) break;
+                if (s0 + k >= n_spans || w.done || hard) break;
                 const uint32_t span_rel = (s0 + k) * kSpan, span_end_rel = span_rel + kSpan;
                 const uint64_t span_start = tile_start + span_rel, span_end = span_start + kSpan;
                 if (w.re >= span_end) {   // no end inside: a fast span
@@ -847,7 +861,17 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
                 const bool in = w.r + (uint64_t)lane < c.R && ends < span_end && ends >= span_start;
                 const uint64_t nin = ~__ballot(in);
                 const uint32_t n = nin ? (uint32_t)__builtin_ctzll(nin) : 64u;
-                if (n == 0 || n >= 64) {
+                if (!SLOW && (n == 0 || n >= 64)) {   // left to the SLOW instantiation, from the tile's start
+                    if (lane == 0) {
+                        uint64_t* sb = (uint64_t*)(uintptr_t)(slow & 0xFFFFFFFFFFFFull);
+                        const uint64_t j = (t >> 2) & (kDenseSubs - 1);
+                        const unsigned long long kk = atomicAdd((unsigned long long*)(sb + ((slow >> 48) & 1ull) * kDenseSubs + j), 1ull);
+                        if (kk < cap) sb[kDenseHeader + j * cap + kk] = t | (r_first << 32);
+                    }
+                    hard = true;
+                    break;
+                }
+                if (SLOW && (n == 0 || n >= 64)) {
                     // 64 ends or more in one span (or a malformed index): the span goes through span_scan, from a settled state
                     settle();
                     w.re_rel = rel_end(w.re, tile_start);
@@ -949,6 +973,7 @@ __global__ __launch_bounds__(256, 3) void dense_kernel(BatchView b, const uint64
                 if (q_tail - q_head >= 64u) drain(64u);
             }
         }
+        if (hard) continue;
         settle();
         if (!w.done) {
             if (w.re == tile_start + tile_valid) {
@@ -1058,33 +1083,51 @@ constexpr uint64_t kSmallBatchBytes = 256ull << 20;
 // with 64 blocks per CU, 3.37 with 8, 3.6 with resident blocks only), then dense_kernel over the tiles it left on the
 // list -- or, for a batch that is dense on average, dense_kernel alone over every tile.  `tn` (ppqc_set_tuning) can
 // force either kernel on every tile and move the thresholds: the results are the same, the tests hold them to each other.
+// Behind every dense_kernel: its SLOW instantiation over the tiles it left on the slow list (a bounded grid with a stride
+// loop; the list is empty for all but pathological inputs, and the launch then costs a few microseconds).
+template <bool LINE>
+static hipError_t launch_dense_slow(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
+                                    Partial* head, Partial* tail, DenseList& sl, uint64_t n_tiles, hipStream_t s) {
+    uint64_t blocks = (n_tiles + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL((dense_kernel<LINE, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base,
+                       head, tail, sl.base, sl.parity, (DenseOut)0);
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) sl.parity ^= 1;   // it leaves the other set of counters at zero for the next launch
+    return e;
+}
+
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
-                              Partial* head, Partial* tail, DenseList& dl, const Tuning& tn, hipStream_t s,
+                              Partial* head, Partial* tail, DenseList& dl, DenseList& sl, const Tuning& tn, hipStream_t s,
                               bool line_mode, bool* dense_alone) {
     if (dense_alone) *dense_alone = false;
     if (b.n_bytes == 0 || b.n_reads == 0) return hipSuccess;
     uint32_t mode = tn.tile_dense < 0 ? 0u : (tn.tile_dense ? 2u : 1u);   // 0 probe every tile, 1 none dense, 2 all dense
-    if (!dl.base) mode = 1;
+    if (!dl.base || !sl.base) mode = 1;
     uint32_t dense_len = tn.dense_len > 0 ? (uint32_t)tn.dense_len : kDenseLen;
     if (dense_len < 16) dense_len = 16;
     uint32_t T = (uint32_t)((1ull << b.tile_shift) / dense_len);
     T = T < 1 ? 1 : (T > 8191 ? 8191 : T);
     const DenseOut dz = make_dense_out(dl.base, dl.parity, mode, T);
+    const DenseOut sz = make_dense_out(sl.base, sl.parity, 0, 1);
     const uint64_t n_tiles = (b.n_bytes + (1ull << b.tile_shift) - 1) >> b.tile_shift;
-    const bool all = tn.tile_all >= 0
+    const bool all = sl.base != nullptr && (tn.tile_all >= 0
                          ? tn.tile_all != 0
-                         : (mode == 0 && b.n_bytes / b.n_reads < (b.n_bytes < kSmallBatchBytes ? kDenseAllLenSmall : kDenseAllLen));
+                         : (mode == 0 && b.n_bytes / b.n_reads < (b.n_bytes < kSmallBatchBytes ? kDenseAllLenSmall : kDenseAllLen)));
     if (all) {
         if (dense_alone) *dense_alone = true;
         uint64_t blocks = (n_tiles + 3) / 4;
         if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
         if (line_mode)
-            hipLaunchKernelGGL((dense_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base,
-                               head, tail, dl.base, dl.parity);
+            hipLaunchKernelGGL((dense_kernel<true, true, false>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra,
+                               read_base, head, tail, dl.base, dl.parity, sz);
         else
-            hipLaunchKernelGGL((dense_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base,
-                               head, tail, dl.base, dl.parity);
-        return hipGetLastError();
+            hipLaunchKernelGGL((dense_kernel<false, true, false>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra,
+                               read_base, head, tail, dl.base, dl.parity, sz);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return line_mode ? launch_dense_slow<true>(b, lut_dev, ra, read_base, head, tail, sl, n_tiles, s)
+                         : launch_dense_slow<false>(b, lut_dev, ra, read_base, head, tail, sl, n_tiles, s);
     }
     if (line_mode) {
         // 4 spans per batch, taken as one group when the line covers them (process_batch), 79 VGPRs = 6 waves per
@@ -1115,15 +1158,17 @@ hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadA
     uint64_t blocks = (bound + 3) / 4;
     if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
     if (line_mode)
-        hipLaunchKernelGGL((dense_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head, tail,
-                           dl.base, dl.parity);
+        hipLaunchKernelGGL((dense_kernel<true, false, false>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra,
+                           read_base, head, tail, dl.base, dl.parity, sz);
     else
-        hipLaunchKernelGGL((dense_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra, read_base, head,
-                           tail, dl.base, dl.parity);
+        hipLaunchKernelGGL((dense_kernel<false, false, false>), dim3((unsigned)blocks), dim3(256), 0, s, b, lut_dev, ra,
+                           read_base, head, tail, dl.base, dl.parity, sz);
     e = hipGetLastError();
+    if (e != hipSuccess) return e;
     // the counters change roles only when a dense_kernel has run: it is what leaves the other counter at zero
-    if (e == hipSuccess) dl.parity ^= 1;
-    return e;
+    dl.parity ^= 1;
+    return line_mode ? launch_dense_slow<true>(b, lut_dev, ra, read_base, head, tail, sl, n_tiles, s)
+                     : launch_dense_slow<false>(b, lut_dev, ra, read_base, head, tail, sl, n_tiles, s);
 }
 
 uint64_t dense_list_words(uint64_t n_tiles) { return kDenseHeader + kDenseSubs * dense_sub_cap(n_tiles); }
