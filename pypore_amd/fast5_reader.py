@@ -79,8 +79,22 @@ def Pathcheck(f5, fail):
     return [p for p in paths if p in visits]
 
 
+SUMMARY_PATH = 'Analyses/Basecall_1D_000/Summary/basecall_1d_template'
+
+
+def albacore_summary(attrs):
+    """(sequence_length, mean_qscore) as albacore wrote them beside the FASTQ record (lib/fast5_reader.py:55-56) -- the
+    values the reference takes on trust.  The GPU path recomputes both from the record itself; the loaders carry these
+    along so that the run can say where the two disagree (seq_routines.albacore_cross_check).  None where absent."""
+    try:
+        ln, mq = attrs.get('sequence_length'), attrs.get('mean_qscore')
+        return (None if ln is None else int(ln), None if mq is None else float(mq))
+    except (TypeError, ValueError, AttributeError):
+        return (None, None)
+
+
 def get_content(f, h5_open=None, p_check=None):
-    """One read (lib/fast5_reader.py:36-71): (mux, start_time, fail, title, bases, quals).  A path containing 'fail'
+    """One read (lib/fast5_reader.py:36-71): (mux, start_time, fail, title, bases, quals, albacore summary).  A path containing 'fail'
     yields no sequence (the reference keeps ReadLength 0, QScore 6.99, GC 0 for it, :37-40, 52).  ``p_check``: the group
     names found by ONE visit of a file of the channel, as the reference passes them in (:96-105); a fail path uses its
     first three entries only."""
@@ -92,12 +106,14 @@ def get_content(f, h5_open=None, p_check=None):
         _channel = _text(f5[dp[1]].attrs['channel_number'])      # read like the reference does; unused there too (:106)
         stamp = _text(f5['Analyses/Segmentation_000'].attrs['time_stamp'])
         title = bases = quals = b""
+        alb = (None, None)
         if not fail:
             lines = _text(f5[dp[4]][()]).split('\n')
             title, bases, quals = lines[0][1:].encode(), lines[1].encode(), lines[3].encode()
             if len(bases) != len(quals):
                 raise ValueError("sequence/quality length mismatch in %s" % f)
-    return mux, int(mktime_local(stamp)), fail, title, bases, quals
+            alb = albacore_summary(f5[dp[3]].attrs)
+    return mux, int(mktime_local(stamp)), fail, title, bases, quals, alb
 
 
 def channel_path_checks(files, h5_open=None):
@@ -124,7 +140,7 @@ def channel_path_checks(files, h5_open=None):
 
 
 def iter_record_batches(files, n_channels=512, threads=1, h5_open=None, batch_reads=4000, job_files=None):
-    """Lists of loader records ``(channel, mux, start_time, fail, title, bases, quals)``, ``batch_reads`` files at a
+    """Lists of loader records ``(channel, mux, start_time, fail, title, bases, quals, albacore)``, ``batch_reads`` files at a
     time.  Unreadable reads are skipped as in the reference's ``except: del ds`` (lib/fast5_reader.py:104-116); a file
     name without a channel field raises like :910.  ``job_files``: all files of the job when ``files`` is one rank's
     share of them -- the probe file of a channel is picked among the job's files, so that every rank (and a run on one
@@ -140,11 +156,11 @@ def iter_record_batches(files, n_channels=512, threads=1, h5_open=None, batch_re
         try:
             if checks.get(ch) is None:
                 raise KeyError("no usable path check for channel %d" % ch)
-            mux, t, fail, title, b, q = get_content(f, h5_open, checks[ch])
+            mux, t, fail, title, b, q, alb = get_content(f, h5_open, checks[ch])
         except (KeyError, IndexError, ValueError, OSError) as e:
             log.debug("skipping %s: %s" % (f, e))
             return None
-        return (ch, mux if 0 <= mux <= 255 else 0, t, 1 if fail else 0, title, b, q)
+        return (ch, mux if 0 <= mux <= 255 else 0, t, 1 if fail else 0, title, b, q, alb)
 
     with ThreadPoolExecutor(max_workers=max(1, int(threads))) as pool:
         for a in range(0, len(files), batch_reads):

@@ -209,6 +209,15 @@ def allreduce_min_int(value, dist, torch, group=None, device="cuda"):
     return int(t.item())
 
 
+def allreduce_sum_ints(values, dist, torch, group=None, device="cuda"):
+    """SUM over the ranks of a few host integers (counts every rank keeps of its own share of a job)."""
+    if _gloo(dist, group):
+        device = "cpu"                                 # see _all_reduce
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return [int(v) for v in t.tolist()]
+
+
 def shard_files(files, rank, world):
     """Contiguous shard of a file list: rank r takes files [r F / N, (r + 1) F / N).  Contiguous, so that the reads of a
     channel keep their order (file order, then record order) when the ranks' outputs are put together in rank order

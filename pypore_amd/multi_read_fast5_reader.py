@@ -6,7 +6,7 @@ from __future__ import annotations
 import os
 from concurrent.futures import ThreadPoolExecutor
 
-from .fast5_reader import default_h5_open, mktime_local, _text, FASTQ_PATH
+from .fast5_reader import default_h5_open, mktime_local, _text, FASTQ_PATH, SUMMARY_PATH, albacore_summary
 from .logging_module import log
 
 
@@ -35,17 +35,22 @@ def read_file(path, h5_open=None):
                 channel = int(_text(f5[r + '/channel_id'].attrs['channel_number']))
                 stamp = _text(f5[r + '/Analyses/Segmentation_000'].attrs['time_stamp'])
                 title = bases = quals = b""
+                alb = (None, None)
                 if not fail:
                     lines = _text(f5[r + '/' + FASTQ_PATH][()]).split('\n')
                     title, bases, quals = lines[0][1:].encode(), lines[1].encode(), lines[3].encode()
                     if len(bases) != len(quals):
                         raise ValueError("sequence/quality length mismatch")
+                    try:    # albacore's own length and mean quality (:104-105), for the cross-check only
+                        alb = albacore_summary(f5[r + '/' + SUMMARY_PATH].attrs)
+                    except KeyError:
+                        pass
             except (KeyError, IndexError, ValueError) as e:
                 # the reference has no handler here and the worker dies; skipping the read keeps the run alive
                 log.warning("skipping %s in %s: %s" % (r, path, e))
                 continue
             recs.append((channel, mux if 0 <= mux <= 255 else 0, int(mktime_local(stamp)), 1 if fail else 0, title,
-                         bases, quals))
+                         bases, quals, alb))
     return recs, ref_start
 
 

@@ -159,15 +159,17 @@ class QCContext:
         return n.value
 
     # -- results ------------------------------------------------------------------------------------
-    def read_stats(self, first=0, n=None):
-        """Per-read records as a dict of numpy arrays; ``err`` is the exact fixed-point sum (Python ints)."""
+    def read_stats(self, first=0, n=None, columns=None):
+        """Per-read records as a dict of numpy arrays; ``err`` is the exact fixed-point sum (Python ints).  ``columns``:
+        only these (the library skips the copies of the others)."""
         if n is None:
             n = self.n_reads - first
         out = dict(length=np.zeros(n, np.uint32), gc=np.zeros(n, np.uint32), n=np.zeros(n, np.uint32),
                    qsum=np.zeros(n, np.int64), mean_q=np.zeros(n, np.float64), err_hi=np.zeros(n, np.uint64),
                    err_lo=np.zeros(n, np.uint64), flags=np.zeros(n, np.uint8))
-        pr = L.PerRead(_ptr(out["length"]), _ptr(out["gc"]), _ptr(out["n"]), _ptr(out["qsum"]), _ptr(out["mean_q"]),
-                       _ptr(out["err_hi"]), _ptr(out["err_lo"]), _ptr(out["flags"]))
+        if columns is not None:
+            out = {k: v for k, v in out.items() if k in columns}
+        pr = L.PerRead(*[_ptr(out.get(k)) for k in ("length", "gc", "n", "qsum", "mean_q", "err_hi", "err_lo", "flags")])
         L.check(self._lib.ppqc_read_stats(self._ctx, C.byref(pr), int(first), int(n)))
         self._keep.clear()
         return out

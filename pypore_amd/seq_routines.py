@@ -722,11 +722,35 @@ def _write_fastq(write_part):
 # Fast5 modes: h5py loaders on the CPU pack CSR batches (lib/seq_routines.py:903-1029)
 # ---------------------------------------------------------------------------------------------------------------
 
+def albacore_cross_check(alb_len, alb_q, length, flags):
+    """Where albacore's own summary attributes and the record disagree.  The reference takes ``sequence_length`` and
+    ``mean_qscore`` on trust (lib/fast5_reader.py:55-56, lib/multi_read_fast5_reader.py:104-105) and fails a read on
+    ``float(mean_qscore) < 7.0`` (:136); this path recomputes length and mean quality from the FASTQ record.  Counts,
+    over the reads whose attributes the loaders found: reads whose ``sequence_length`` is not the number of bases, and
+    reads whose fail decision differs.  A cross-check, not an input: the tables are the record's."""
+    alb_len, alb_q = np.asarray(alb_len, np.int64), np.asarray(alb_q, np.float64)
+    has_len, has_q = alb_len >= 0, ~np.isnan(alb_q)
+    out = dict(reads_with_attributes=int((has_len | has_q).sum()),
+               length_mismatch=int((has_len & (alb_len != np.asarray(length, np.int64))).sum()),
+               fail_mismatch=int((has_q & ((alb_q < 7.0) != ((np.asarray(flags) & 1) != 0))).sum()))
+    if out["reads_with_attributes"]:
+        log.debug("albacore summary attributes on %(reads_with_attributes)d reads: sequence_length differs from the record "
+                  "on %(length_mismatch)d, the fail decision (mean_qscore < 7.0) on %(fail_mismatch)d" % out)
+        if out["length_mismatch"] or out["fail_mismatch"]:
+            log.warning("albacore's sequence_length / mean_qscore disagree with the FASTQ records on %d / %d reads; "
+                        "the tables follow the records" % (out["length_mismatch"], out["fail_mismatch"]))
+    return out
+
+
+ALBACORE_CHECK = None    # the last Fast5 run's cross-check (also in the returned stats as stats["albacore_check"])
+
+
 def _tables_from_loader(record_batches, ref_time, Fast_flag, compat_flags=0):
     """``record_batches``: iterable of lists of loader records.  A loader thread packs each list straight into a pinned
     host slot (staging.pack_records) while the previous batch is copied and reduced."""
+    global ALBACORE_CHECK
     from .staging import Stage, pack_records
-    kept = []
+    kept, alb = [], []
     with qc.QCContext(device=device, n_channels=n_channels, n_mux=4, n_time_bins=n_hours, bin_seconds=3600,
                       time_mode=1, tz_offset_s=local_tz_offset(), ref_time_s=int(ref_time), fail_q=7.0,
                       compat_flags=compat_flags) as ctx:
@@ -735,6 +759,7 @@ def _tables_from_loader(record_batches, ref_time, Fast_flag, compat_flags=0):
 
         def submit(b, d):
             ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["start_time"], b["fail_flag"], slot=d)
+            alb.append((b["albacore_len"], b["albacore_q"]))
             if Fast_flag:   # -fq keeps the reads: out of the pinned slot, which is about to be refilled
                 kept.append({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in b.items()})
             return True
@@ -743,6 +768,18 @@ def _tables_from_loader(record_batches, ref_time, Fast_flag, compat_flags=0):
             stage.run(record_batches, fill, submit)
         ctx.sync()
         per_read = ctx.read_stats() if Fast_flag else None
+        ALBACORE_CHECK = None
+        mine = dict(reads_with_attributes=0, length_mismatch=0, fail_mismatch=0)
+        if alb and any((a >= 0).any() or (~np.isnan(q)).any() for a, q in alb):
+            pr = per_read if per_read is not None else ctx.read_stats(columns=("length", "flags"))
+            mine = albacore_cross_check(np.concatenate([a for a, _ in alb]), np.concatenate([q for _, q in alb]),
+                                        pr["length"], pr["flags"])
+        if DIST is not None:      # every rank has checked its own share: the job's counts are their sums
+            from .merge import allreduce_sum_ints
+            keys = sorted(mine)
+            mine = dict(zip(keys, allreduce_sum_ints([mine[k] for k in keys], DIST[0], DIST[1])))
+        if mine["reads_with_attributes"]:
+            ALBACORE_CHECK = mine
         tables = finalize_run(ctx)
     return tables, per_read, kept
 
@@ -770,6 +807,7 @@ def fast5module(work_dir_, file_folder, prefix_, tmp_dir, Fast_flag, size, h5_op
         return ChannelOut, None, None
     plates = result_plotting(ChannelOut)
     stats = FastStats(ChannelOut)
+    stats["albacore_check"] = ALBACORE_CHECK
     return ChannelOut, stats, plates
 
 
@@ -800,6 +838,7 @@ def multifast5reader(work_dir_, file_folder, prefix_, tmp_dir, Fast_flag, size, 
         return ChannelOut, None, None
     plates = result_plotting(ChannelOut)
     stats = FastStats(ChannelOut)
+    stats["albacore_check"] = ALBACORE_CHECK
     return ChannelOut, stats, plates
 
 

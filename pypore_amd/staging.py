@@ -81,7 +81,7 @@ class PinnedSlot:
 
 
 def pack_records(recs, slot=None):
-    """CSR batch from loader records ``(channel, mux, start_time, fail, title, bases, quals)`` -- into the pinned slot's
+    """CSR batch from loader records ``(channel, mux, start_time, fail, title, bases, quals[, albacore])`` -- into the pinned slot's
     arenas when one is given (each read is copied once, from the bytes h5py returned into page-locked memory), else
     into fresh arrays."""
     n = len(recs)
@@ -109,6 +109,11 @@ def pack_records(recs, slot=None):
     v["fail_flag"][:] = [r[3] for r in recs]
     v["n_reads"] = n
     v["titles"] = [r[4] for r in recs]
+    # albacore's sequence_length / mean_qscore where the loader found them (-1 / NaN where not): host-side only, for the
+    # cross-check of seq_routines.albacore_cross_check; never handed to the library
+    alb = [r[7] if len(r) > 7 and r[7] is not None else (None, None) for r in recs]
+    v["albacore_len"] = np.array([-1 if a[0] is None else a[0] for a in alb], np.int64)
+    v["albacore_q"] = np.array([np.nan if a[1] is None else a[1] for a in alb], np.float64)
     return v
 
 

@@ -49,23 +49,29 @@ class FakeH5:
         pass
 
 
-def write_single(path, read_number, channel, mux, stamp, exp_start, fastq=None):
+def write_single(path, read_number, channel, mux, stamp, exp_start, fastq=None, summary=None):
+    """summary: (sequence_length, mean_qscore) as albacore writes them beside the record (None: the group without them)."""
     attrs = {"Raw/Reads/Read_%d" % read_number: {"start_mux": mux, "read_id": "id%d" % read_number},
              "UniqueGlobalKey/channel_id": {"channel_number": str(channel)},
              "UniqueGlobalKey/tracking_id": {"exp_start_time": exp_start},
              "Analyses/Segmentation_000": {"time_stamp": stamp}}
     data = {}
     if fastq is not None:
-        attrs["Analyses/Basecall_1D_000/Summary/basecall_1d_template"] = {"sequence_length": 0, "mean_qscore": 0.0}
+        attrs["Analyses/Basecall_1D_000/Summary/basecall_1d_template"] = \
+            {} if summary is None else {"sequence_length": int(summary[0]), "mean_qscore": float(summary[1])}
         data["Analyses/Basecall_1D_000/BaseCalled_template/Fastq"] = fastq
     with open(path, "w") as fh:
         json.dump({"attrs": attrs, "datasets": data}, fh)
 
 
 def write_multi(path, reads, exp_start):
-    """reads: list of (name, channel, mux, stamp, fastq_or_None)."""
+    """reads: list of (name, channel, mux, stamp, fastq_or_None[, (sequence_length, mean_qscore)])."""
     attrs, data = {}, {}
-    for name, channel, mux, stamp, fastq in reads:
+    for rd in reads:
+        name, channel, mux, stamp, fastq = rd[:5]
+        if len(rd) > 5 and rd[5] is not None:
+            attrs[name + "/Analyses/Basecall_1D_000/Summary/basecall_1d_template"] = \
+                {"sequence_length": int(rd[5][0]), "mean_qscore": float(rd[5][1])}
         attrs[name + "/Raw"] = {"start_mux": mux}
         attrs[name + "/channel_id"] = {"channel_number": str(channel)}
         attrs[name + "/tracking_id"] = {"exp_start_time": exp_start}

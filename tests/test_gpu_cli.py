@@ -211,8 +211,15 @@ def test_fast5_modes_on_stand_in_hdf5(tmp_path, monkeypatch):
         r["fail"] = r["i"] % 7 == 0
         d = tmp_path / ("s/fail/0" if r["fail"] else "s/pass/0")
         fq = None if r["fail"] else "@read%d\n%s\n+\n%s\n" % (r["i"], r["seq"].decode(), r["qual"].decode())
+        # albacore's own summary attributes (lib/fast5_reader.py:55-56): consistent with the record, but for two reads --
+        # one whose sequence_length is off by one, one whose mean_qscore lies on the other side of 7.0 -- and absent on some
+        mq = _mean_q(r["qual"])
+        r["summary"] = None if r["i"] % 5 == 0 else (len(r["seq"]) + (1 if r["i"] == 11 else 0),
+                                                      (9.0 if mq < 7.0 else 6.5) if r["i"] == 12 else mq)
         fake_h5.write_single(str(d / ("x_read_%d_ch_%d_strand.fast5" % (r["i"], r["ch"]))), r["i"], r["ch"], r["mux"],
-                             _iso(base, r["sec"]), exp, fq)
+                             _iso(base, r["sec"]), exp, fq, r["summary"])
+    assert not recs[11]["fail"] and not recs[12]["fail"]
+    n_attr = sum(1 for r in recs if not r["fail"] and r["summary"] is not None)
     ref = f5r.mktime_local(exp)
     times = [int(f5r.mktime_local(_iso(base, r["sec"]))) for r in recs]
     ref_cd = _ref_shaped(recs, ref, sq.local_tz_offset(), times=times)
@@ -222,6 +229,7 @@ def test_fast5_modes_on_stand_in_hdf5(tmp_path, monkeypatch):
     cd, stats, plates = sq.run([str(tmp_path), str(tmp_path / "s"), "one", "res1", "1", "True", "2", "False", "None", "False"])
     assert watch.calls and all(c == ("csr", True) for c in watch.calls)       # CSR batches packed in pinned slots
     _check_stats(stats, po.FastStats_data(ref_cd))
+    assert stats["albacore_check"] == dict(reads_with_attributes=n_attr, length_mismatch=1, fail_mismatch=1)
     _check_html_contract(str(tmp_path / "res1"), "one", stats, per=10)
     assert plates == po.result_plotting_data(ref_cd)
     for c in range(1, 513):
@@ -236,7 +244,7 @@ def test_fast5_modes_on_stand_in_hdf5(tmp_path, monkeypatch):
     bad = [r for r in recs if r["fail"]]
     def entry(r, with_fq):
         fq = "@read%d\n%s\n+\n%s\n" % (r["i"], r["seq"].decode(), r["qual"].decode()) if with_fq else None
-        return ("read_%04d" % r["i"], r["ch"], r["mux"], _iso(base, r["sec"]), fq)
+        return ("read_%04d" % r["i"], r["ch"], r["mux"], _iso(base, r["sec"]), fq, r["summary"] if with_fq else None)
     fake_h5.write_multi(str(tmp_path / "m" / "pass" / "a.fast5"), [entry(r, True) for r in good[:100]], exp)
     fake_h5.write_multi(str(tmp_path / "m" / "pass" / "b.fast5"), [entry(r, True) for r in good[100:]], exp)
     fake_h5.write_multi(str(tmp_path / "m" / "fail" / "c.fast5"), [entry(r, False) for r in bad], exp)
@@ -251,6 +259,7 @@ def test_fast5_modes_on_stand_in_hdf5(tmp_path, monkeypatch):
         any(ref_cd_m[str(c)][2] == 0 for c in singles)
     assert po.FastStats_data(ref_cd_m)["table"] != po.FastStats_data(ref_cd)["table"]     # the branch matters here
     _check_stats(stats2, po.FastStats_data(ref_cd_m))
+    assert stats2["albacore_check"] == dict(reads_with_attributes=n_attr, length_mismatch=1, fail_mismatch=1)
     assert plates2 == plates
     for c in range(1, 513):
         e, r = cd2[str(c)], ref_cd_m[str(c)]
