@@ -223,10 +223,13 @@ int ppqc_submit_records(ppqc_ctx* ctx, const ppqc_records* host_records);
  * albacore header fields ch= / start_time= (0 / INT64_MIN if absent, as ppqc_fastq_pack), every read gets `mux`.
  * The number of records appended is returned in *n_records.  Malformed records (no '@', no '+', differing captions,
  * sequence and quality lengths differ) are detected on the device: the call itself fails if the line count is not a
- * multiple of 4, otherwise ppqc_fetch_tables / ppqc_read_stats fail with the first bad record's number.  Not checked
- * here (SeqIO would raise; ppqc_fastq_scan/pack do check): blanks inside a sequence line, quality bytes outside
- * '!'..'~' (clamped as in ppqc_submit).  The host variant copies through staging slot 0|1 like ppqc_submit; the
- * device variant needs a 16-byte aligned pointer. */
+ * multiple of 4, otherwise ppqc_fetch_tables / ppqc_read_stats fail with the first bad record's number.  White space
+ * where SeqIO (lib/seq_routines.py:49-50) and ppqc_fastq_scan refuse it -- blanks or tabs inside a sequence line, white
+ * space inside a quality line, a bare CR anywhere but at a line end -- is found by a balance over the whole text (every
+ * white-space byte the scan pass sees must be a stripped line end or lie in a title) and fails the same two calls,
+ * without a record number; a \v or \f inside a sequence line, which SeqIO would take for a base, is refused as well.
+ * Quality bytes outside '!'..'~' are counted (ppqc_input_errors) and clamped as in ppqc_submit.  The host variant
+ * copies through staging slot 0|1 like ppqc_submit; the device variant needs a 16-byte aligned pointer. */
 int ppqc_submit_fastq(ppqc_ctx* ctx, const uint8_t* host_text, uint64_t n, int slot, uint8_t mux, uint64_t* n_records);
 int ppqc_submit_fastq_device(ppqc_ctx* ctx, const uint8_t* device_text, uint64_t n, uint8_t mux, uint64_t* n_records);
 int ppqc_sync(ppqc_ctx* ctx);
@@ -236,11 +239,12 @@ int ppqc_sync(ppqc_ctx* ctx);
  * counterpart is the worker pool pulling the next task while results are still being merged, lib/seq_routines.py:916-942).
  * Returns at once if the slot has not been used. */
 int ppqc_slot_wait(ppqc_ctx* ctx, int slot);
-/* Input problems found on the device since create / reset: out[0] malformed rows of device CSR batches, out[1]
- * malformed FASTQ records, out[2] number of the first of those within its text (UINT64_MAX if none), out[3] quality
- * bytes outside '!'..'~' seen by the GPU tokenizer (reported like n_bad_qual of ppqc_fastq_pack; [0] and [1] also make
- * ppqc_fetch_tables / ppqc_read_stats fail).  Synchronises. */
-int ppqc_input_errors(ppqc_ctx* ctx, uint64_t* out4);
+/* Input problems found on the device since create / reset, five words: out[0] malformed rows of device CSR batches,
+ * out[1] malformed FASTQ records, out[2] number of the first of those within its text (UINT64_MAX if none), out[3]
+ * quality bytes outside '!'..'~' seen by the GPU tokenizer (reported like n_bad_qual of ppqc_fastq_pack), out[4] the
+ * white-space balance of the FASTQ texts (see ppqc_submit_fastq; 0 when every white-space byte is where it may be).
+ * [0], [1] and [4] also make ppqc_fetch_tables / ppqc_read_stats fail.  Synchronises. */
+int ppqc_input_errors(ppqc_ctx* ctx, uint64_t* out5);
 
 int ppqc_n_reads(ppqc_ctx* ctx, uint64_t* n);
 /* Per-read records [first, first+n) (the ChrList entries of lib/fast5_reader.py:127, minus the hour). */

@@ -283,6 +283,10 @@ static int input_errors(const uint64_t* e) {
         return fail(PPQC_E_INVALID, "malformed FASTQ: " + std::to_string(e[1]) + " bad records, the first is record " +
                                         std::to_string(e[2]) + " of its text (header without '@', third line without '+', "
                                         "differing captions, or sequence and quality lengths differ)");
+    if (e[6])
+        return fail(PPQC_E_INVALID, "malformed FASTQ: " + std::to_string((int64_t)e[6]) + " white-space bytes inside sequence "
+                                        "or quality lines, or bare CR line ends (SeqIO refuses them; ppqc_fastq_scan names "
+                                        "the record)");
     return PPQC_OK;
 }
 
@@ -422,7 +426,7 @@ static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     HIPCHK(hipMemset(c->res_buf + c->res_words, 0, 16));
     HIPCHK(hipMemset(c->res_buf + c->res_words + 2, 0xFF, 8));
     HIPCHK(hipMemset(c->res_buf + c->res_words + 3, 0, (5 + kGateWords) * 8));   // [3] bad quality bytes, [8..] sort gate
-    HIPCHK(hipHostMalloc((void**)&c->res_host, (c->res_words + 4) * 8, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->res_host, (c->res_words + 8) * 8, hipHostMallocDefault));
     c->sum_buf = c->res_buf;
     c->sel_buf = c->sum_buf + tp.lay.n_sum;
     c->max_buf = c->sel_buf + PPQC_N_SEL;
@@ -695,7 +699,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
         const uint64_t cap = n_chunks + n_chunks / 4 + 64;
         CHK(grow(&c->fq.counts, 0, cap, s)); CHK(grow(&c->fq.n_entries, 0, cap, s));
         CHK(grow(&c->fq.entries, 0, cap * kNlEntriesPerChunk, s));
-        CHK(grow(&c->fq.prefix, 0, cap + 2, s));
+        CHK(grow(&c->fq.prefix, 0, cap + 3, s));
         CHK(grow(&c->fq.block_sums, 0, nl_scan_block_words(cap), s));
         CHK(grow(&c->fq.span_sum, 0, cap * 2 * (kNlChunk / kSpan), s));
         c->cap_chunks = cap;
@@ -742,10 +746,10 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     if (hdr_aux) {
         HIPCHK(hipEventRecord(c->ev_fq, s));
         HIPCHK(hipStreamWaitEvent(c->aux, c->ev_fq, 0));
-        HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, c->aux));
+        HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, c->fq.prefix + n_chunks + 2, c->res_buf + c->res_words, c->aux));
         HIPCHK(hipEventRecord(c->ev_hdr, c->aux));
     } else {
-        HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, s));
+        HIPCHK(launch_fastq_header(text, R, c->fq.line_off, c->ra, c->n_reads, mux, c->fq.prefix + n_chunks + 2, c->res_buf + c->res_words, s));
     }
     if (from_sums) {
         HIPCHK(launch_line_sums(text, n, R, c->fq.line_off, c->fq.span_sum, c->lut_dev, c->lra, s));
@@ -899,10 +903,13 @@ int ppqc_slot_wait(ppqc_ctx* c, int si) {
     return PPQC_OK;
 }
 
-int ppqc_input_errors(ppqc_ctx* c, uint64_t* out4) {
-    if (!c || !out4) return fail(PPQC_E_INVALID, "null argument");
+int ppqc_input_errors(ppqc_ctx* c, uint64_t* out5) {
+    if (!c || !out5) return fail(PPQC_E_INVALID, "null argument");
     CHK(ppqc_sync(c));
-    HIPCHK(hipMemcpy(out4, c->res_buf + c->res_words, 32, hipMemcpyDeviceToHost));
+    uint64_t e[7];
+    HIPCHK(hipMemcpy(e, c->res_buf + c->res_words, 56, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) out5[k] = e[k];
+    out5[4] = e[6];
     return PPQC_OK;
 }
 
@@ -917,8 +924,8 @@ int ppqc_read_stats(ppqc_ctx* c, const ppqc_per_read* o, uint64_t first, uint64_
     if (first + n > c->n_reads) return fail(PPQC_E_INVALID, "read range out of bounds");
     CHK(ppqc_sync(c));
     if (n == 0) return PPQC_OK;
-    uint64_t bad[3] = {0, 0, 0};
-    HIPCHK(hipMemcpy(bad, c->res_buf + c->res_words, 24, hipMemcpyDeviceToHost));
+    uint64_t bad[7] = {0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpy(bad, c->res_buf + c->res_words, 56, hipMemcpyDeviceToHost));
     CHK(input_errors(bad));
     const ReadArrays& r = c->ra;
 #define D2H(dst, src, T) \
@@ -1072,7 +1079,7 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
 // pinned mirror, on `st`.  When the mirror holds the cells already (cmh_on_host: 2 x cells words, by far the largest
 // part, copied beside the per-read kernel), only what lies in front of them and behind them is copied.
 static int copy_results(ppqc_ctx* c, hipStream_t st) {
-    const uint64_t end = c->res_words + 3;
+    const uint64_t end = c->res_words + 7;   // with the seven error words
     if (!c->cmh_on_host) {
         HIPCHK(hipMemcpyAsync(c->res_host, c->res_buf, end * 8, hipMemcpyDeviceToHost, st));
         return PPQC_OK;
@@ -1142,7 +1149,7 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     // The N50 word of the mirror lies outside the copied range (the spare word behind the error words), so the copy,
     // which carries the device's not yet final n50_out along, cannot overwrite it.
     const bool early_out = early_fetch && c->state == 2 && ss != s;
-    uint64_t* host_out = early_out ? c->res_host + c->res_words + 3 : nullptr;
+    uint64_t* host_out = early_out ? c->res_host + c->res_words + 7 : nullptr;
     if (pre) {
         HIPCHK(hipEventSynchronize(c->ev_pre));   // a wait of the host while the GPU is busy with the tile kernel
         const uint64_t m = c->maxlen_host[4];
@@ -1216,7 +1223,7 @@ static int fetch_tables_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
     o->max_len = mx[0];
     o->min_pos_len = mn[0];
     o->lin_bin_width = mx[0] / PPQC_N_LEN_LIN + 1;
-    o->n50 = c->n50 = n50_in_mirror ? h[c->res_words + 3] : (mn + 1 + nch)[2];
+    o->n50 = c->n50 = n50_in_mirror ? h[c->res_words + 7] : (mn + 1 + nch)[2];
     c->fin_pending = true;   // timings: see resolve_finalize_timings
     return PPQC_OK;
 }

@@ -29,6 +29,12 @@ __device__ __forceinline__ uint32_t nl_mask(uint32_t v) {
     return ~t;
 }
 
+__device__ __forceinline__ uint32_t cr_mask(uint32_t v) {   // the same for '\r'
+    const uint32_t x = v ^ 0x0D0D0D0Du;
+    const uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu;
+    return ~t;
+}
+
 // 16-bit mask (bit k = byte k of the lane's 16-byte vector is a newline), bytes at or beyond `valid` cleared
 __device__ __forceinline__ uint32_t vec_nl_bits(const uint4& v, int valid) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -62,6 +68,27 @@ __device__ __forceinline__ uint32_t vec_badq_bits(const uint4& v, int valid) {
     }
     if (valid < 16) bits &= valid <= 0 ? 0u : ((1u << valid) - 1u);
     return bits;
+}
+
+// high bit of each byte set where the byte is ASCII white space (blank, \t \n \v \f \r): what rstrip() removes at a line end
+__device__ __forceinline__ uint32_t ws_mask(uint32_t x) {
+    const uint32_t H = 0x80808080u, hi = x & H, lo7 = x & 0x7F7F7F7Fu;
+    const uint32_t ge9 = (lo7 + 0x77777777u) & H, ge14 = (lo7 + 0x72727272u) & H, ge32 = (lo7 + 0x60606060u) & H;
+    const uint32_t ge33 = (lo7 + 0x5F5F5F5Fu) & H;
+    return ((ge9 & ~ge14) | (ge32 & ~ge33)) & ~hi;
+}
+// number of white-space bytes among the first `valid` bytes of the vector
+__device__ __forceinline__ uint32_t vec_ws_count(const uint4& v, int valid) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t m = ws_mask(w[k]);
+        const int left = valid - 4 * k;   // bytes of this word that count
+        if (left < 4) m &= left <= 0 ? 0u : ((1u << (8 * left)) - 1u);
+        c += __popc(m);
+    }
+    return c;
 }
 
 // true iff some byte of the 16-byte vector lies outside '!'..'~' (newlines, other white space and invalid quality bytes);
@@ -134,6 +161,7 @@ __global__ __launch_bounds__(256) void nl_scan_kernel(const uint8_t* __restrict_
         vv[it] = load_vec_clamped(text, pos < n ? pos : 0, n);
     }
     uint32_t cnt = 0, ne = 0;   // ne: wave-uniform
+    uint32_t wsn = 0;           // white-space bytes, newlines included (see fastq_finalize_kernel: the white-space balance)
     uint64_t s0 = 0, s1 = 0;    // SUMS: lane `it` keeps the words of span `it`
 #pragma unroll
     for (int it = 0; it < kIt; ++it) {
@@ -146,6 +174,7 @@ __global__ __launch_bounds__(256) void nl_scan_kernel(const uint8_t* __restrict_
             const uint64_t rem = n - pos;
             bits = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
             if (NOTES) bad = vec_badq_bits(v, rem < 16 ? (int)rem : 16);
+            wsn += vec_ws_count(v, rem < 16 ? (int)rem : 16);
         }
         cnt += __popc(bits);
         const uint64_t odd = NOTES ? __ballot((bits | bad) != 0) : 0ull;
@@ -182,8 +211,9 @@ __global__ __launch_bounds__(256) void nl_scan_kernel(const uint8_t* __restrict_
         o[0] = s0; o[1] = s1;
     }
     cnt = wave_sum_u32(cnt);
+    wsn = wave_sum_u32(wsn) - cnt;   // at most 8192 each
     if (lane == 0) {
-        counts[chunk] = cnt;
+        counts[chunk] = cnt | (wsn << 16);
         n_entries[chunk] = NOTES ? ne : (uint32_t)kNlEntries + 1u;   // no notes: as if the list had overflowed
         if (NOTES && ne > (uint32_t)kNlEntries) atomicAdd((unsigned long long*)overflow, 1ull);
     }
@@ -192,20 +222,24 @@ __global__ __launch_bounds__(256) void nl_scan_kernel(const uint8_t* __restrict_
 constexpr int kScanBlock = 2048;   // entries per block of the two-level scan
 uint64_t nl_scan_block_words(uint64_t n_chunks) { return (n_chunks + kScanBlock - 1) / kScanBlock + 2; }
 
+// counts[i] = newlines of chunk i | its other white-space bytes << 16; the latter are only added up (*ws_total)
 __global__ __launch_bounds__(256) void nl_blocksum_kernel(const uint32_t* __restrict__ counts, uint64_t n,
-                                                          uint64_t* __restrict__ bsum) {
+                                                          uint64_t* __restrict__ bsum, uint64_t* __restrict__ ws_total) {
     __shared__ unsigned long long acc;
     if (threadIdx.x == 0) acc = 0;
     __syncthreads();
-    uint64_t t = 0;
+    uint64_t t = 0;   // both sums in one word: a block's chunks hold at most 2^24 bytes
     for (int k = 0; k < kScanBlock / 256; ++k) {
         const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)k * 256 + threadIdx.x;
-        if (i < n) t += counts[i];
+        if (i < n) { const uint32_t c = counts[i]; t += (uint64_t)(c & 0xFFFFu) | ((uint64_t)(c >> 16) << 32); }
     }
     t = wave_sum_u64(t);
     if ((threadIdx.x & 63) == 0) atomicAdd(&acc, (unsigned long long)t);
     __syncthreads();
-    if (threadIdx.x == 0) bsum[blockIdx.x] = acc;
+    if (threadIdx.x == 0) {
+        bsum[blockIdx.x] = acc & 0xFFFFFFFFull;
+        if (acc >> 32) atomicAdd((unsigned long long*)ws_total, acc >> 32);
+    }
 }
 
 // single block: exclusive scan of the block sums in place; grand total -> *total
@@ -248,7 +282,7 @@ __global__ __launch_bounds__(256) void nl_scan_apply_kernel(const uint32_t* __re
     uint32_t v[8];
     uint64_t loc = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { v[k] = b0 + k < n ? counts[b0 + k] : 0; loc += v[k]; }
+    for (int k = 0; k < 8; ++k) { v[k] = b0 + k < n ? counts[b0 + k] & 0xFFFFu : 0; loc += v[k]; }
     part[t] = loc;
     __syncthreads();
     if (t == 0) {
@@ -380,11 +414,12 @@ __global__ __launch_bounds__(256) void nl_fill_kernel(const uint8_t* __restrict_
 
 
 // Pass 1 and the scan: counts, entries and the chunks' line numbers; fs.prefix[n_chunks] = newlines of the text,
-// fs.prefix[n_chunks + 1] = chunks whose entry list overflowed.
+// fs.prefix[n_chunks + 1] = chunks whose entry list overflowed, fs.prefix[n_chunks + 2] = white-space bytes of the text
+// other than newlines.
 hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& fs, uint64_t* host_out, hipEvent_t counted,
                           hipStream_t s, const uint64_t* lut_dev, bool notes) {
     const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
-    hipError_t e = hipMemsetAsync(fs.prefix + n_chunks, 0, 16, s);
+    hipError_t e = hipMemsetAsync(fs.prefix + n_chunks, 0, 24, s);
     if (e != hipSuccess || n_chunks == 0) return e;
     if (lut_dev)   // with span sums (fs.span_sum holds two words per 1 KiB span of every chunk)
         hipLaunchKernelGGL(nl_scan_kernel<true>, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, text, n, fs.counts,
@@ -398,7 +433,8 @@ hipError_t launch_nl_scan(const uint8_t* text, uint64_t n, const FastqScratch& f
                            fs.counts, fs.n_entries, fs.entries, n_chunks, fs.prefix + n_chunks + 1, (uint64_t*)nullptr,
                            (const uint64_t*)nullptr);
     const uint64_t nblocks = (n_chunks + kScanBlock - 1) / kScanBlock;
-    hipLaunchKernelGGL(nl_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, fs.counts, n_chunks, fs.block_sums);
+    hipLaunchKernelGGL(nl_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, fs.counts, n_chunks, fs.block_sums,
+                       fs.prefix + n_chunks + 2);
     hipLaunchKernelGGL(nl_scan_top_kernel, dim3(1), dim3(256), 0, s, fs.block_sums, nblocks, fs.prefix + n_chunks, host_out,
                        text + n - 1);
     if (counted) {   // the host may go on from here while the chunks' line numbers are written
@@ -502,36 +538,64 @@ struct HeaderScan {
     }
 };
 
+// The kernel also keeps the WHITE-SPACE BALANCE of the text (errors[6], see fastq_finalize_kernel): it adds the count
+// of the scan pass (*ws_seen: every blank, \t, \v, \f and \r of the text) and takes off the blanks, tabs, \v and \f of the
+// header lines, which may hold them anywhere (the title is free text to SeqIO; a \r inside it is a bare CR line end, which
+// the host packer refuses).  The keys end the search early, the count goes on to the end of the line by words.
 __global__ __launch_bounds__(256) void fastq_header_kernel(const uint8_t* __restrict__ text, uint64_t n_records,
                                                            const uint64_t* __restrict__ lo, ReadArrays ra,
-                                                           uint64_t read_base, uint8_t mux) {
+                                                           uint64_t read_base, uint8_t mux,
+                                                           const uint64_t* __restrict__ ws_seen,
+                                                           uint64_t* __restrict__ errors) {
+    __shared__ unsigned int blanks_acc;
+    if (threadIdx.x == 0) blanks_acc = 0;
+    __syncthreads();
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_records) return;
-    const uint64_t g = read_base + r;
-    const uint64_t a = lo[4 * r], e0 = lo[4 * r + 1];
-    const int64_t len = (int64_t)(e0 - a);
-    const uintptr_t base = (uintptr_t)(text + a), endp = (uintptr_t)(text + e0);
-    uintptr_t ga = base & ~(uintptr_t)15;
-    int64_t k = -(int64_t)(base & 15u);   // index in the header of the granule's first byte
-    HeaderScan h;
-    uint4 cur = make_uint4(0, 0, 0, 0);
-    if (ga < endp) cur = *reinterpret_cast<const uint4*>(ga);
-    while (ga < endp) {
-        const uintptr_t gn = ga + 16;
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (gn < endp) nxt = *reinterpret_cast<const uint4*>(gn);
-        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+    uint32_t blanks = 0;
+    if (r < n_records) {
+        const uint64_t g = read_base + r;
+        const uint64_t a = lo[4 * r], e0 = lo[4 * r + 1];
+        const int64_t len = (int64_t)(e0 - a);
+        const uintptr_t base = (uintptr_t)(text + a), endp = (uintptr_t)(text + e0);
+        uintptr_t ga = base & ~(uintptr_t)15;
+        int64_t k = -(int64_t)(base & 15u);   // index in the header of the granule's first byte
+        HeaderScan h;
+        uint4 cur = make_uint4(0, 0, 0, 0);
+        if (ga < endp) cur = *reinterpret_cast<const uint4*>(ga);
+        while (ga < endp) {
+            const uintptr_t gn = ga + 16;
+            uint4 nxt = make_uint4(0, 0, 0, 0);
+            if (gn < endp) nxt = *reinterpret_cast<const uint4*>(gn);
+            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+            if (!h.done()) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int64_t kk = k + t;
-            if (kk >= 1 && kk < len) h.step((w[t >> 2] >> (8 * (t & 3))) & 0xffu);   // byte 0 is the '@'
+                for (int t = 0; t < 16; ++t) {
+                    const int64_t kk = k + t;
+                    if (kk >= 1 && kk < len) h.step((w[t >> 2] >> (8 * (t & 3))) & 0xffu);   // byte 0 is the '@'
+                }
+            }
+            // white space of the granule's bytes that lie in the line, the line end's \r and \n left out
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t k0 = k + 4 * q;   // index in the header of the word's first byte
+                uint32_t m = ws_mask(w[q]) & ~nl_mask(w[q]) & ~cr_mask(w[q]);
+                if (k0 < 0) m &= k0 <= -4 ? 0u : ~((1u << (8 * (int)(-k0))) - 1u);
+                if (k0 + 4 > len) m &= k0 >= len ? 0u : ((1u << (8 * (int)(len - k0))) - 1u);
+                blanks += __popc(m);
+            }
+            cur = nxt; ga = gn; k += 16;
         }
-        if (h.done()) break;
-        cur = nxt; ga = gn; k += 16;
+        ra.channel[g] = h.ch;
+        ra.mux[g] = mux;
+        ra.time[g] = h.time();
     }
-    ra.channel[g] = h.ch;
-    ra.mux[g] = mux;
-    ra.time[g] = h.time();
+    blanks = wave_sum_u32(blanks);
+    if ((threadIdx.x & 63) == 0 && blanks) atomicAdd(&blanks_acc, blanks);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint64_t delta = (blockIdx.x == 0 ? *ws_seen : 0ull) - (uint64_t)blanks_acc;
+        if (delta) atomicAdd((unsigned long long*)&errors[6], (unsigned long long)delta);
+    }
 }
 
 // ---- line sums from the span sums of the scan pass ------------------------------------------------------------------------
@@ -696,16 +760,15 @@ __global__ __launch_bounds__(256) void line_sum_kernel(const uint8_t* __restrict
     line_finish<true>(q, text, n, 4 * r + 3, span_sum, lut, lane, lra);
 }
 
+// record r of the text; returns the white-space bytes it has placed (see below)
 template <bool WHOLE>
-__global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __restrict__ text, uint64_t n,
-                                                             uint64_t n_records, const uint64_t* __restrict__ lo,
-                                                             ReadArrays lra, ReadArrays ra, uint64_t read_base,
-                                                             const Partial* __restrict__ head,
-                                                             const Partial* __restrict__ tail, uint32_t tile_shift,
-                                                             const uint64_t* __restrict__ lut, QThr thr,
-                                                             uint8_t mux, uint64_t* __restrict__ errors) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_records) return;
+__device__ __forceinline__ uint32_t fastq_finalize_record(const uint8_t* __restrict__ text, uint64_t r,
+                                                          const uint64_t* __restrict__ lo, const ReadArrays& lra,
+                                                          const ReadArrays& ra, uint64_t read_base,
+                                                          const Partial* __restrict__ head,
+                                                          const Partial* __restrict__ tail, uint32_t tile_shift,
+                                                          const uint64_t* __restrict__ lut, const QThr& thr,
+                                                          uint64_t* __restrict__ errors) {
     const uint64_t g = read_base + r;
     uint64_t a[4], e[4];
     uint64_t strip_qb = 0, strip_err = 0;   // what the stripped end of the quality line added to its raw sums
@@ -723,11 +786,19 @@ __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __re
 #pragma unroll
         for (int j = 0; j < kTailBytes; ++j) tb[k][j] = e[k] >= a[k] + (uint64_t)j + 1 ? text[e[k] - 1 - j] : (uint8_t)'x';
     const uint8_t first0 = e[0] > a[0] ? text[a[0]] : (uint8_t)0, first2 = e[2] > a[2] ? text[a[2]] : (uint8_t)0;
+    // The white-space balance (errors[6]): the scan pass has counted every white-space byte of the text, line ends
+    // included as far as they are not '\n'; what is stripped here and what a title may hold is taken off again (the
+    // title line's own blanks by fastq_header_kernel).  Whatever remains lies INSIDE a sequence or quality line, or is
+    // a '\r' inside a title: SeqIO refuses blanks and tabs in a sequence and white space as a quality, and a bare CR
+    // is a line end to it (lib/seq_routines.py:49-50; ppqc_fastq_scan refuses the same).
+    uint32_t placed = 0;
+    auto place = [&](int k, uint8_t ch) { placed += ch != '\n' && (k != 0 || ch == '\r'); };
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         int j = 0;
         while (j < kTailBytes && is_space(tb[k][j])) {   // '\n', "\r\n", trailing blanks: what rstrip() removes
             if (k == 3) { strip_qb += tb[k][j]; strip_err += lut[tb[k][j]]; }
+            place(k, tb[k][j]);
             ++j;
         }
         e[k] -= (uint64_t)j;
@@ -735,14 +806,20 @@ __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __re
             while (e[k] > a[k] && is_space(text[e[k] - 1])) {
                 --e[k];
                 if (k == 3) { strip_qb += text[e[k]]; strip_err += lut[text[e[k]]]; }
+                place(k, text[e[k]]);
             }
     }
     const uint64_t L = e[1] - a[1];
     bool ok = e[0] > a[0] && first0 == '@' && e[2] > a[2] && first2 == '+' && L == e[3] - a[3] && L < 0xFFFFFFFFull;
     if (ok && e[2] - a[2] > 1) {   // an optional repeated title must match (SeqIO: "captions differ")
         ok = e[2] - a[2] == e[0] - a[0];
-        for (uint64_t i = 1; ok && i < e[2] - a[2]; ++i) ok = text[a[2] + i] == text[a[0] + i];
+        for (uint64_t i = 1; ok && i < e[2] - a[2]; ++i) {
+            const uint8_t ch = text[a[2] + i];
+            ok = ch == text[a[0] + i];
+            placed += is_space(ch) && ch != '\r';   // as in the title
+        }
     }
+
     uint64_t gcs = 0, nn = 0, qb = 0, hi = 0, lw = 0;
     if (!ok) {
         atomicAdd((unsigned long long*)&errors[1], 1ull);
@@ -777,13 +854,34 @@ __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __re
         ra.channel[g] = 0;
         ra.time[g] = INT64_MIN;
     }
+    return placed;
+}
+
+template <bool WHOLE>
+__global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                             uint64_t n_records, const uint64_t* __restrict__ lo,
+                                                             ReadArrays lra, ReadArrays ra, uint64_t read_base,
+                                                             const Partial* __restrict__ head,
+                                                             const Partial* __restrict__ tail, uint32_t tile_shift,
+                                                             const uint64_t* __restrict__ lut, QThr thr,
+                                                             uint8_t mux, uint64_t* __restrict__ errors) {
+    __shared__ unsigned int placed_acc;
+    if (threadIdx.x == 0) placed_acc = 0;
+    __syncthreads();
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t placed = 0;
+    if (r < n_records) placed = fastq_finalize_record<WHOLE>(text, r, lo, lra, ra, read_base, head, tail, tile_shift, lut, thr, errors);
+    placed = wave_sum_u32(placed);
+    if ((threadIdx.x & 63) == 0 && placed) atomicAdd(&placed_acc, placed);
+    __syncthreads();   // one atomic per block: the balance is one word
+    if (threadIdx.x == 0 && placed_acc) atomicAdd((unsigned long long*)&errors[6], 0ull - (unsigned long long)placed_acc);
 }
 
 hipError_t launch_fastq_header(const uint8_t* text, uint64_t n_records, const uint64_t* line_off, ReadArrays ra,
-                               uint64_t read_base, uint8_t mux, hipStream_t s) {
+                               uint64_t read_base, uint8_t mux, const uint64_t* ws_seen, uint64_t* errors, hipStream_t s) {
     if (n_records == 0) return hipSuccess;
     hipLaunchKernelGGL(fastq_header_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n_records,
-                       line_off, ra, read_base, mux);
+                       line_off, ra, read_base, mux, ws_seen, errors);
     return hipGetLastError();
 }
 

@@ -209,7 +209,7 @@ hipError_t launch_nl_place(const uint8_t* text, uint64_t n, uint64_t n_lines, ui
 // parses ch= and start_time= out of the header.  errors[1] counts malformed records.
 // channel, mux and start time of every record from its header line (needs the line table only)
 hipError_t launch_fastq_header(const uint8_t* text, uint64_t n_records, const uint64_t* line_off, ReadArrays ra,
-                               uint64_t read_base, uint8_t mux, hipStream_t s);
+                               uint64_t read_base, uint8_t mux, const uint64_t* ws_seen, uint64_t* errors, hipStream_t s);
 hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
                                  ReadArrays line_ra, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint32_t tile_shift, const uint64_t* lut, const QThr& thr,

@@ -431,8 +431,9 @@ hipError_t launch_records(ReadArrays ra, uint64_t read_base, uint64_t n, const u
     return hipGetLastError();
 }
 
-// the four input-error words behind the results: [0] bad CSR rows, [1] bad FASTQ records, [2] first of them, [3] bad
-// quality bytes; [8 .. 8 + kGateWords) the sort gate (OR of the sort keys of the run, raised by finalize_reads)
+// the input-error words behind the results: [0] bad CSR rows, [1] bad FASTQ records, [2] first of them, [3] bad
+// quality bytes, [6] the white-space balance of the FASTQ texts ([4], [5]: length bound and ticket);
+// [8 .. 8 + kGateWords) the sort gate (OR of the sort keys of the run, raised by finalize_reads)
 // `tail` > 0: the words behind the results (input errors, length bound and ticket, sort gate) are reset as well
 // (all zero but the number of the first bad FASTQ record): ppqc_reset clears everything with one launch.
 __global__ void init_results_kernel(uint64_t* res, uint64_t n_sum, uint64_t nch1, uint32_t tail) {

@@ -122,12 +122,14 @@ class QCContext:
         return n.value
 
     def input_errors(self):
-        """dict(bad_csr_rows, bad_fastq_records, first_bad_record, bad_quality_bytes) found on the device so far."""
-        out = np.zeros(4, np.uint64)
+        """dict(bad_csr_rows, bad_fastq_records, first_bad_record, bad_quality_bytes, misplaced_whitespace) found on
+        the device so far."""
+        out = np.zeros(5, np.uint64)
         L.check(self._lib.ppqc_input_errors(self._ctx, _ptr(out)))
         first = int(out[2])
         return dict(bad_csr_rows=int(out[0]), bad_fastq_records=int(out[1]),
-                    first_bad_record=None if first == (1 << 64) - 1 else first, bad_quality_bytes=int(out[3]))
+                    first_bad_record=None if first == (1 << 64) - 1 else first, bad_quality_bytes=int(out[3]),
+                    misplaced_whitespace=int(out[4].astype(np.int64)))
 
     def submit_records(self, length, mean_q, channel, mux, start_time_s, gc_count=None):
         """Reads whose statistics come from a table (albacore sequencing_summary.txt, lib/seq_routines.py:831-863)."""

@@ -159,7 +159,8 @@ def test_invalid_quality_bytes_are_counted_like_the_host_packer(qc_mod):
     with qc_mod.QCContext(device=0, **CFG) as ctx:
         ctx.submit_fastq(text)
         e = ctx.input_errors()
-        assert e == dict(bad_csr_rows=0, bad_fastq_records=0, first_bad_record=None, bad_quality_bytes=want)
+        assert e == dict(bad_csr_rows=0, bad_fastq_records=0, first_bad_record=None, bad_quality_bytes=want,
+                         misplaced_whitespace=0)
         ctx.finalize()                 # reported, not fatal (the bytes are clamped as in ppqc_submit)
         ctx.reset()
         assert ctx.input_errors()["bad_quality_bytes"] == 0
@@ -299,7 +300,7 @@ def test_fuzzed_texts_around_span_edges(qc_mod, c_oracle, seed):
     """Random texts aimed at the span sums: lines that start or end on, just before or just behind a 1 KiB span edge,
     lines inside one span, empty lines, lines of many spans; quality lines of nothing but bytes at or above '@' (the scan
     pass then takes them for sequence and the line sums must come from the text), sequence lines with bytes below '@',
-    blanks inside lines (a span without sums inside a line), headers longer than a span, LF / CRLF, with and without the
+    invalid bytes inside lines (a span without sums inside a line), headers longer than a span, LF / CRLF, with and without the
     last line end.  Both ways of making the line sums against the host packer and the oracle."""
     rng = np.random.default_rng(1000 + seed)
     crlf = bool(seed % 2)
@@ -332,7 +333,7 @@ def test_fuzzed_texts_around_span_edges(qc_mod, c_oracle, seed):
         if L > 50 and kind == 7:
             seq = seq.copy()
             seq[rng.integers(0, L, 3)] = np.frombuffer(b"*-.", np.uint8)       # bytes below '@' inside a sequence
-            qual[rng.integers(0, L - 1, 2)] = 32                                # blanks inside (not at the end of) a quality line
+            qual[rng.integers(0, L - 1, 2)] = 31                                # invalid bytes inside a quality line
         rec = b"@" + title + nl + bytes(seq) + nl + b"+" + nl + bytes(qual) + nl
         out.append(rec); pos += len(rec)
     text = b"".join(out)
@@ -346,6 +347,95 @@ def test_fuzzed_texts_around_span_edges(qc_mod, c_oracle, seed):
         tables = ctx.finalize()
     _check(got, want)
     assert_tables_equal(tables, wt, str(seed))
+
+
+def _host_verdict(text):
+    """True iff the host packer (ppqc_fastq_scan / ppqc_fastq_pack, which follow SeqIO) takes the text without complaint:
+    a malformed record raises, a quality byte outside '!'..'~' is counted and makes the CLI raise."""
+    from pypore_amd import fastq_io
+    try:
+        return fastq_io.pack_fastq(text)["n_bad_qual"] == 0
+    except ValueError:
+        return False
+
+
+def _gpu_verdict(qc_mod, text):
+    from pypore_amd._lib import PPQCError
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        try:
+            ctx.submit_fastq(text)
+            e = ctx.input_errors()
+            ctx.read_stats()
+            ctx.finalize()
+        except PPQCError as err:
+            assert "FASTQ" in str(err)
+            return False, str(err)
+        assert e["bad_fastq_records"] == 0 and e["misplaced_whitespace"] == 0
+        return e["bad_quality_bytes"] == 0, ""
+
+
+@pytest.mark.parametrize("rec", [
+    b"@r ch=1\nAC GT\n+\nIIIII\n",        # a blank inside the sequence (SeqIO: "Whitespace is not allowed in the sequence")
+    b"@r ch=1\nAC\tGT\n+\nIIIII\n",       # a tab
+    b"@r ch=1\n ACGT\n+\nIIIII\n",        # at its start
+    b"@r ch=1\nAC\rGT\n+\nIIIII\n",       # a bare CR is a line end to SeqIO (universal newlines): not supported
+    b"@r ch=1\nACGT\n+\nII\rI\n",         # ... inside the quality line
+    b"@r\rch=1\nACGT\n+\nIIII\n",         # ... inside the title
+    b"@r ch=1\nACGT\n+\nII I\n",          # a blank as a quality
+    b"@r ch=1\nACGT\n+\nII\x0bI\n",       # a vertical tab as a quality
+    b"@r ch=1\r\nAC GT\r\n+\r\nIIIII\r\n",
+])
+@pytest.mark.parametrize("n_before", [0, 40])
+def test_white_space_where_seqio_refuses_it(qc_mod, rec, n_before):
+    """the two cases the header used to list as not checked are failures now, with the host packer's
+    verdict; the records around the bad one are fine and the context works again after a reset."""
+    from pypore_amd._lib import PPQCError
+    good = _text(5, n_before, crlf=b"\r\n" in rec) if n_before else b""
+    text = good + rec + good
+    assert _host_verdict(good + good) and not _host_verdict(text)
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        assert ctx.submit_fastq(text) == 2 * n_before + 1
+        assert ctx.input_errors()["misplaced_whitespace"] == 1
+        with pytest.raises(PPQCError, match="white-space"):
+            ctx.finalize()
+        with pytest.raises(PPQCError, match="white-space"):
+            ctx.read_stats()
+        ctx.reset()
+        assert ctx.submit_fastq(good + b"@r \t\x0b x\r\nACGT \r\n+\t\r\nIIII\x0c\r\n") == n_before + 1
+        assert ctx.input_errors()["misplaced_whitespace"] == 0      # all of it in the title or stripped at a line end
+        assert int(ctx.finalize()["totals"][0]) == n_before + 1
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_white_space_fuzz_has_the_host_packers_verdict(qc_mod, seed):
+    """Texts of short and long records with white-space bytes dropped in at random places -- in front of, inside and at
+    the end of each of the four lines -- are accepted or refused exactly as the host packer does (blank, tab, CR
+    anywhere; \\v and \\f anywhere but inside a sequence line, where SeqIO takes them for bases and this tokenizer,
+    which cannot tell which line a misplaced byte lies in, refuses them: include/pypore_qc.h)."""
+    rng = np.random.default_rng(500 + seed)
+    agree = {True: 0, False: 0}
+    for case in range(40):
+        crlf = bool(rng.integers(0, 2))
+        nl = b"\r\n" if crlf else b"\n"
+        recs = []
+        for i in range(int(rng.integers(1, 30))):
+            L = int(rng.choice([1, 2, 17, 300, 1100, 5000, 20000]))
+            title = b"r%d ch=%d start_time=2018-06-03T%02d:00:00Z" % (i, int(rng.integers(1, 513)), int(rng.integers(0, 24)))
+            recs.append([b"@" + title, bytes(rng.choice(ALPH, L)), b"+" + (title if rng.integers(0, 4) == 0 else b""),
+                         bytes(rng.integers(33, 127, L, dtype=np.uint8))])
+        for _ in range(int(rng.integers(0, 3))):          # 0, 1 or 2 bytes dropped in
+            r = recs[int(rng.integers(0, len(recs)))]
+            k = int(rng.integers(0, 4))
+            ch = bytes([int(rng.choice([32, 9, 13] if k == 1 else [32, 9, 13, 11, 12]))])
+            where = int(rng.integers(0, 3))
+            at = 0 if where == 0 else (len(r[k]) if where == 1 else int(rng.integers(0, len(r[k]) + 1)))
+            r[k] = r[k][:at] + ch + r[k][at:]
+        text = nl.join(nl.join(r) for r in recs) + (nl if rng.integers(0, 2) else b"")
+        want = _host_verdict(text)
+        got, msg = _gpu_verdict(qc_mod, text)
+        assert got == want, (seed, case, msg, text[:200])
+        agree[want] += 1
+    assert agree[True] >= 5 and agree[False] >= 5
 
 
 _BIG = {}
