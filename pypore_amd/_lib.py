@@ -31,7 +31,7 @@ SYMBOLS = (
     "ppqc_finalize_tables", "ppqc_finalize_n50", "ppqc_fetch_tables", "ppqc_fetch_tables_view", "ppqc_finalize", "ppqc_finalize_view", "ppqc_device_tables_view",
     "ppqc_timings", "ppqc_reset_timings", "ppqc_sort_u32_device", "ppqc_sort_u32_device_static", "ppqc_synth_fill_device", "ppqc_fastq_scan", "ppqc_fastq_pack",
     "ppqc_submit_fastq", "ppqc_submit_fastq_device", "ppqc_input_errors", "ppqc_time_range", "ppqc_set_ref_time", "ppqc_n50_select_hist", "ppqc_n50_select_pick", "ppqc_index_early", "ppqc_stream_wait_index", "ppqc_n50_select_early", "ppqc_cells_early", "ppqc_set_stream",
-    "ppqc_mode1_dist_view", "ppqc_mode1_dist_phase", "ppqc_slot_wait", "ppqc_compat_dist_count", "ppqc_bind_thread", "ppqc_set_tuning",
+    "ppqc_mode1_dist_view", "ppqc_mode1_dist_phase", "ppqc_slot_wait", "ppqc_compat_dist_count", "ppqc_bind_thread", "ppqc_set_tuning", "ppqc_path_count",
     "ppqc_group_create", "ppqc_group_finalize", "ppqc_group_destroy",
 )
 
@@ -156,7 +156,7 @@ def load():
         "ppqc_group_destroy": [P],
         "ppqc_mode1_dist_view": [P, C.POINTER(Mode1Tables)], "ppqc_mode1_dist_phase": [P, C.c_int],
         "ppqc_compat_dist_count": [P, C.POINTER(P), C.POINTER(C.c_uint64)], "ppqc_bind_thread": [P],
-        "ppqc_set_tuning": [P, C.c_char_p, C.c_int],
+        "ppqc_set_tuning": [P, C.c_char_p, C.c_int], "ppqc_path_count": [P, C.c_char_p, C.POINTER(C.c_uint64)],
         "ppqc_fastq_scan": [P, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "ppqc_fastq_pack": [P, C.c_uint64, C.c_uint64, P, P, P, P, P, P, P, C.POINTER(C.c_uint64)],
     }

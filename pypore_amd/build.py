@@ -6,7 +6,9 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ["ppqc_api.hip", "ppqc_tile.hip", "ppqc_tables.hip", "ppqc_sort.hip", "ppqc_synth.hip", "ppqc_fastq_gpu.hip", "ppqc_fastq.cpp"]
+SRC = ["ppqc_api.hip", "ppqc_tile.hip", "ppqc_tables.hip", "ppqc_sort.hip", "ppqc_synth.hip", "ppqc_fastq_gpu.hip", "ppqc_fastq1.hip",
+       "ppqc_fastq.cpp"]
+HDR = ["ppqc_internal.hpp", "ppqc_fastq_dev.hpp"]
 OUT = os.path.join(HERE, "libpypore_qc.so")
 
 
@@ -14,7 +16,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(HERE, "csrc", s) for s in SRC + ["ppqc_internal.hpp"]]
+    deps = [os.path.join(HERE, "csrc", s) for s in SRC + HDR]
     deps.append(os.path.join(HERE, "..", "include", "pypore_qc.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -24,7 +26,7 @@ def source_hash():
     profile's HBM counters only when it equals the hash of the sources the running library was built from."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(SRC + ["ppqc_internal.hpp"]):
+    for f in sorted(SRC + HDR):
         h.update(f.encode())
         h.update(open(os.path.join(HERE, "csrc", f), "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "pypore_qc.h"), "rb").read())
@@ -48,7 +50,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "csrc", "build")
     os.makedirs(objdir, exist_ok=True)
-    common = [os.path.join(HERE, "csrc", "ppqc_internal.hpp"), os.path.join(HERE, "..", "include", "pypore_qc.h")]
+    common = [os.path.join(HERE, "csrc", h) for h in HDR] + [os.path.join(HERE, "..", "include", "pypore_qc.h")]
     t_common = max(os.path.getmtime(d) for d in common)
     jobs, objs = [], []
     for s in SRC:

@@ -157,6 +157,9 @@ struct ppqc_ctx {
     FastqScratch fq{};
     ReadArrays lra{};           // rec_* only: raw sums per text line
     uint64_t cap_chunks = 0, cap_lines = 0;
+    Fq1Scratch fq1{};           // the one-pass kernels (ppqc_fastq1.hip)
+    uint64_t cap_fq1_lines = 0, cap_fq1_regions = 0;
+    uint64_t n_fq1 = 0, n_fq1_declined = 0, n_fq_general = 0;   // ppqc_path_count
     int64_t fq_line_hint = -1;  // mean bytes per line of the last FASTQ text (-1: none yet); a hint for the scan pass only
 
     std::vector<EvPair> pending;
@@ -483,7 +486,8 @@ int ppqc_destroy(ppqc_ctx* c) {
     void* ptrs[] = {r.rec_cnt, r.rec_hi, r.rec_lo, r.len, r.gc, r.nn, r.qsum, r.mean_q, r.err_hi, r.err_lo, r.flags,
                     r.channel, r.mux, r.time, r.hour, r.lens32, c->head, c->tail, c->res_buf, c->sk32, c->sk32_tmp, c->counts, c->vals, c->vals_tmp, c->sk64,
                     c->sk64_tmp, c->n50_blocks, c->chan_start, c->first_desc, c->lut_dev, c->dense.base, c->slow.base, c->fq.counts, c->fq.n_entries, c->fq.entries, c->fq.prefix,
-                    c->fq.block_sums, c->fq.line_off, c->fq.span_sum, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo, c->m1, c->cc, c->tab_slab};
+                    c->fq.block_sums, c->fq.line_off, c->fq.span_sum, c->lra.rec_cnt, c->lra.rec_hi, c->lra.rec_lo, c->m1, c->cc, c->tab_slab,
+                    c->fq1.points, c->fq1.regions, c->fq1.head};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->maxlen_host) (void)hipHostFree(c->maxlen_host);
@@ -690,10 +694,74 @@ int ppqc_submit(ppqc_ctx* c, const ppqc_batch* b, int si) {
 // 10 kb 1.65 / 1.27 (4 GB).
 constexpr int64_t kFastqSumsMinLine = 768;
 constexpr int64_t kFastqNotesMinLine = 320;   // below: more than 25 line ends per 8 KiB chunk on average, the notes hold 32 vectors
+// Mean bytes per line for which the one-pass kernels (ppqc_fastq1.hip) are taken: above, the span sums read little more
+// than the text once as well and do less arithmetic per byte; below, a region's lines outgrow its share of the point table.
+constexpr int64_t kFq1MinLine = 160, kFq1MaxLine = kFastqSumsMinLine;
+
+static void fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_records) {
+    c->n_reads += R;
+    c->state = 0;
+    c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
+    c->pre_ok = false;
+    c->cells_early = c->cells_done = c->cmh_on_host = false;
+    c->bases_total += n;     // the text holds every base
+    if (n_records) *n_records = R;
+}
+
+static int fastq_line_count_error(uint64_t n_lines) {
+    return fail(PPQC_E_INVALID, "FASTQ text has " + std::to_string(n_lines) + " lines, not a multiple of 4 (blank "
+                                    "lines or multi-line records: use ppqc_fastq_scan / ppqc_fastq_pack)");
+}
+
+// One pass over the text (ppqc_fastq1.hip).  *done = false: the text is not for these kernels (reads of a few bases
+// somewhere in it); nothing has been committed and the caller takes the general path.
+static int run_fastq_one_pass(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, uint64_t* n_records, bool* done) {
+    *done = false;
+    hipStream_t s = c->stream;
+    uint32_t cpr = 1;
+    uint64_t n_regions = 1;
+    fq1_shape(n, c->tn.fq1_regions, &cpr, &n_regions);
+    const uint64_t need_lines = n_regions * cpr * kFq1LinesPerChunk;
+    if (need_lines > c->cap_fq1_lines) {
+        const uint64_t cap = need_lines + need_lines / 4;
+        CHK(grow(&c->fq1.points, 0, cap * 4, s));
+        c->cap_fq1_lines = cap;
+    }
+    if (n_regions > c->cap_fq1_regions) {
+        CHK(grow(&c->fq1.regions, 0, n_regions + 64, s));
+        c->cap_fq1_regions = n_regions + 64;
+    }
+    if (!c->fq1.head) CHK(grow(&c->fq1.head, 0, 2, s));
+    uint64_t* h = c->maxlen_host;   // pinned scratch words: [1] lines, [2] flags
+    HIPCHK(launch_fq1_scan(text, n, c->fq1, cpr, n_regions, c->lut_dev, h + 1, s));
+    HIPCHK(hipEventRecord(c->ev_fq, s));
+    HIPCHK(hipEventSynchronize(c->ev_fq));
+    const uint64_t n_lines = h[1];
+    c->fq_line_hint = n_lines ? (int64_t)(n / n_lines) : -1;
+    if (h[2] != 0) { ++c->n_fq1_declined; return PPQC_OK; }
+    ++c->n_fq1;
+    if (n_lines % 4 != 0) return fastq_line_count_error(n_lines);
+    const uint64_t R = n_lines / 4;
+    if (R >= (1ull << 30)) return fail(PPQC_E_RANGE, "more than 2^30-1 records in one text");
+    CHK(ensure_reads(c, c->n_reads + R));
+    HIPCHK(launch_fq1_finalize(text, n, R, c->fq1, cpr, n_regions, c->ra, c->n_reads, c->lut_dev, c->qthr, mux,
+                               c->res_buf + c->res_words, s));
+    fastq_committed(c, R, n, n_records);
+    *done = true;
+    return PPQC_OK;
+}
+
 static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, uint64_t* n_records) {
     if (n_records) *n_records = 0;
     if (n == 0) return PPQC_OK;
     hipStream_t s = c->stream;
+    const int op = c->tn.fastq_one_pass;
+    if (op == 1 || (op < 0 && c->fq_line_hint >= kFq1MinLine && c->fq_line_hint < kFq1MaxLine)) {
+        bool done = false;
+        CHK(run_fastq_one_pass(c, text, n, mux, n_records, &done));
+        if (done) return PPQC_OK;
+    }
+    ++c->n_fq_general;
     const uint64_t n_chunks = (n + kNlChunk - 1) / kNlChunk;
     if (n_chunks > c->cap_chunks) {
         const uint64_t cap = n_chunks + n_chunks / 4 + 64;
@@ -721,9 +789,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     const uint64_t n_over = notes ? h[2] : n_chunks;   // chunks with more line ends than their notes hold
     c->fq_line_hint = n_lines ? (int64_t)(n / n_lines) : -1;
     const bool from_sums = with_sums && (fs_mode == 2 || c->fq_line_hint >= kFastqSumsMinLine);
-    if (n_lines % 4 != 0)
-        return fail(PPQC_E_INVALID, "FASTQ text has " + std::to_string(n_lines) + " lines, not a multiple of 4 (blank "
-                                        "lines or multi-line records: use ppqc_fastq_scan / ppqc_fastq_pack)");
+    if (n_lines % 4 != 0) return fastq_line_count_error(n_lines);
     const uint64_t R = n_lines / 4;
     if (R >= (1ull << 30)) return fail(PPQC_E_RANGE, "more than 2^30-1 records in one text");
     if (n_lines > c->cap_lines) {
@@ -761,13 +827,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     if (hdr_aux) HIPCHK(hipStreamWaitEvent(s, c->ev_hdr, 0));
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
                                  c->lut_dev, c->qthr, mux, c->res_buf + c->res_words, s, from_sums));
-    c->n_reads += R;
-    c->state = 0;
-    c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
-    c->pre_ok = false;
-    c->cells_early = c->cells_done = c->cmh_on_host = false;
-    c->bases_total += n;     // the text holds every base
-    if (n_records) *n_records = R;
+    fastq_committed(c, R, n, n_records);
     return PPQC_OK;
 }
 
@@ -1418,6 +1478,7 @@ int ppqc_set_tuning(ppqc_ctx* c, const char* name, int value) {
         {"tile_all", &c->tn.tile_all, -1, 1},           {"tile_shift", &c->tn.tile_shift, -1, kMaxTileShift},
         {"pre", &c->tn.pre, -1, 1},                     {"fastq_sums", &c->tn.fastq_sums, -1, 2},
         {"fastq_hdr_aux", &c->tn.fastq_hdr_aux, -1, 2}, {"sort_beside", &c->tn.sort_beside, -1, 1},
+        {"fastq_one_pass", &c->tn.fastq_one_pass, -1, 1}, {"fq1_regions", &c->tn.fq1_regions, -1, 1 << 20},
     };
     for (auto& k : knobs)
         if (strcmp(name, k.n) == 0) {
@@ -1427,6 +1488,15 @@ int ppqc_set_tuning(ppqc_ctx* c, const char* name, int value) {
             return PPQC_OK;
         }
     return fail(PPQC_E_INVALID, std::string("ppqc_set_tuning: unknown knob ") + name);
+}
+
+int ppqc_path_count(ppqc_ctx* c, const char* name, uint64_t* out) {
+    if (!c || !name || !out) return fail(PPQC_E_INVALID, "null argument");
+    if (strcmp(name, "fastq_one_pass") == 0) *out = c->n_fq1;
+    else if (strcmp(name, "fastq_declined") == 0) *out = c->n_fq1_declined;
+    else if (strcmp(name, "fastq_general") == 0) *out = c->n_fq_general;
+    else return fail(PPQC_E_INVALID, std::string("ppqc_path_count: unknown counter ") + name);
+    return PPQC_OK;
 }
 
 int ppqc_bind_thread(ppqc_ctx* c) {

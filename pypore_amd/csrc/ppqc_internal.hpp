@@ -105,6 +105,8 @@ struct Tuning {
     int sort_beside = -1;   // 1: the sort + N50 chain starts behind the batches' index kernels, beside the per-read kernel; 0: at
                             // that kernel's end; -1: beside it when it is dense_kernel alone (ppqc_finalize_n50)
     int fastq_hdr_aux = -1; // FASTQ text: 0 header kernel in front of the line pass, 2 beside it, -1 / 1 beside line_sum only
+    int fastq_one_pass = -1;  // FASTQ text: 1 the one-pass kernels of ppqc_fastq1.hip for every text, 0 never, -1 by the last text's lines
+    int fq1_regions = -1;     // ... the number of regions (waves) they split a text into (4096)
 };
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
                               Partial* head, Partial* tail, DenseList& dl, DenseList& slow, const Tuning& tn, hipStream_t s,
@@ -214,6 +216,23 @@ hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_rec
                                  ReadArrays line_ra, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint32_t tile_shift, const uint64_t* lut, const QThr& thr,
                                  uint8_t mux, uint64_t* errors, hipStream_t s, bool whole_lines = false);
+
+// ---- FASTQ text of short lines in one pass (ppqc_fastq1.hip) ---------------------------------------------------------
+constexpr uint32_t kFq1LinesPerChunk = 64;       // share of the point table per 8 KiB chunk of a region (lines)
+constexpr uint64_t kFq1MaxRegionChunks = 2048;   // a region holds at most 2^24 bytes (24-bit positions in the points)
+struct Fq1Region { uint64_t lines, gcs, n, odd, qb, err_a, err_b, flags; };   // totals, then exclusive prefix over the regions
+struct Fq1Scratch {
+    uint64_t* points;      // 4 words per line end, kFq1LinesPerChunk per chunk
+    Fq1Region* regions;
+    uint64_t* head;        // lines of the text, flags (1: a chunk with too many newline vectors, 2: a region with too many lines)
+};
+uint64_t fq1_chunks(uint64_t n);
+void fq1_shape(uint64_t n, int want_regions, uint32_t* cpr, uint64_t* n_regions);
+hipError_t launch_fq1_scan(const uint8_t* text, uint64_t n, const Fq1Scratch& f, uint32_t cpr, uint64_t n_regions,
+                           const uint64_t* lut_dev, uint64_t* host_out, hipStream_t s);
+hipError_t launch_fq1_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const Fq1Scratch& f, uint32_t cpr,
+                               uint64_t n_regions, ReadArrays ra, uint64_t read_base, const uint64_t* lut_dev,
+                               const QThr& thr, uint8_t mux, uint64_t* errors, hipStream_t s);
 
 hipError_t launch_synth(uint8_t* bases, uint8_t* quals, uint64_t first, uint64_t n, uint64_t seed, hipStream_t s);
 

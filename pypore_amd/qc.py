@@ -356,6 +356,12 @@ class QCContext:
         -1 gives the choice back to the library."""
         L.check(self._lib.ppqc_set_tuning(self._ctx, name.encode(), int(value)))
 
+    def path_count(self, name):
+        """How many FASTQ texts took the named code path (ppqc_path_count)."""
+        n = C.c_uint64()
+        L.check(self._lib.ppqc_path_count(self._ctx, name.encode(), C.byref(n)))
+        return n.value
+
     def bind_thread(self):
         """The context's GPU becomes the calling thread's current device (loader threads that allocate pinned memory)."""
         L.check(self._lib.ppqc_bind_thread(self._ctx))

@@ -13,14 +13,18 @@ CFG = dict(n_channels=512, n_mux=4, n_time_bins=48, bin_seconds=3600, time_mode=
 ALPH = np.frombuffer(b"ACGTACGTNnacgtSs", np.uint8)
 
 
-@pytest.fixture(autouse=True, params=["0", "2", "1"], ids=["second_pass", "span_sums", "auto"])
+WAYS = {"second_pass": {"fastq_sums": 0, "fastq_one_pass": 0}, "span_sums": {"fastq_sums": 2, "fastq_one_pass": 0},
+        "auto": {"fastq_sums": 1}, "one_pass": {"fastq_one_pass": 1}, "one_pass_3_regions": {"fastq_one_pass": 1, "fq1_regions": 3}}
+
+
+@pytest.fixture(autouse=True, params=list(WAYS), ids=list(WAYS))
 def line_sums_from(request, monkeypatch):
-    """Every test runs both ways the line sums are made: the line-mode tile kernel's second pass over the text
-    (ppqc_set_tuning fastq_sums = 0), the span sums of the scan pass put together per line (2), and the library's own choice
-    (1, the default: by the mean line length of the context's previous text -- span sums for long lines, a scan that only
-    counts for very short ones)."""
+    """Every test runs every way the library has of turning text into per-read sums: the line-mode tile kernel's second
+    pass over the text (ppqc_set_tuning fastq_sums = 0), the span sums of the scan pass put together per line (2), the
+    one-pass kernels of ppqc_fastq1.hip (fastq_one_pass = 1; with 3 regions a wave walks many chunks and the records
+    straddle regions), and the library's own choice (by the mean line length of the context's previous text)."""
     from pypore_amd import qc
-    monkeypatch.setattr(qc.QCContext, "DEFAULT_TUNING", {"fastq_sums": int(request.param)})
+    monkeypatch.setattr(qc.QCContext, "DEFAULT_TUNING", dict(WAYS[request.param]))
     return request.param
 
 
@@ -42,6 +46,12 @@ def _text(seed, n, crlf=False, trailing=True, plus_title=False, lens=None, field
         out.append(b"@" + title + nl + seq + nl + b"+" + (title.rstrip() if plus_title else b"") + nl + qual + nl)
     t = b"".join(out)
     return t if trailing else t[:-len(nl)]
+
+
+def _took(ctx, way):
+    """With the one-pass kernels forced, a text they are made for must not have been handed to the general path."""
+    if way.startswith("one_pass"):
+        assert ctx.path_count("fastq_one_pass") == 1 and ctx.path_count("fastq_declined") == 0
 
 
 def _host_path(qc, c_oracle, text):
@@ -201,7 +211,7 @@ def test_dense_text_takes_the_second_text_pass(qc_mod, c_oracle):
         assert_tables_equal(ctx.finalize(), wt2)
 
 
-def test_lines_that_end_on_span_group_and_tile_edges_and_odd_headers(qc_mod, c_oracle):
+def test_lines_that_end_on_span_group_and_tile_edges_and_odd_headers(qc_mod, c_oracle, line_sums_from):
     """The line-mode tile kernel takes four 1 KiB spans at once when the line covers them: lines that end exactly on a
     4 KiB group edge, a 1 KiB span edge or a 64 KiB tile edge, and lines a few bytes off them.  The header kernel works on
     240-byte windows in LDS: longer headers (the one-lane walk), keys at the very start, behind a tab, inside other
@@ -239,6 +249,7 @@ def test_lines_that_end_on_span_group_and_tile_edges_and_odd_headers(qc_mod, c_o
         assert ctx.submit_fastq(text) == 160
         got = ctx.read_stats()
         tables = ctx.finalize()
+        _took(ctx, line_sums_from)
     _check(got, want)
     assert_tables_equal(tables, wt)      # channels and start times: the host packer's, through the tables
     assert int(tables["totals"][7]) == int(np.sum((p["channel"] < 1) | (p["channel"] > 512))) > 0
@@ -296,7 +307,7 @@ def test_a_run_of_short_reads_inside_long_ones(qc_mod, c_oracle):
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PPQC_FUZZ_SEEDS", "10"))))   # more for a longer run
-def test_fuzzed_texts_around_span_edges(qc_mod, c_oracle, seed):
+def test_fuzzed_texts_around_span_edges(qc_mod, c_oracle, seed, line_sums_from):
     """Random texts aimed at the span sums: lines that start or end on, just before or just behind a 1 KiB span edge,
     lines inside one span, empty lines, lines of many spans; quality lines of nothing but bytes at or above '@' (the scan
     pass then takes them for sequence and the line sums must come from the text), sequence lines with bytes below '@',
@@ -345,6 +356,7 @@ def test_fuzzed_texts_around_span_edges(qc_mod, c_oracle, seed):
         assert ctx.submit_fastq(text) == len(out)
         got = ctx.read_stats()
         tables = ctx.finalize()
+        _took(ctx, line_sums_from)
     _check(got, want)
     assert_tables_equal(tables, wt, str(seed))
 
@@ -456,7 +468,7 @@ def _big_text():
     return _BIG["text"], _BIG["n"], _BIG["nb"]
 
 
-def test_a_text_of_long_reads_at_size(qc_mod, c_oracle):
+def test_a_text_of_long_reads_at_size(qc_mod, c_oracle, line_sums_from):
     """0.4 GB of text, 20 000 reads with the length distribution of BASELINE config 2 (lognormal, mean 10 kb, up to
     hundreds of kb): every record and table against the host packer + C oracle, however the line sums are made."""
     text, n_reads, nb = _big_text()
@@ -468,6 +480,39 @@ def test_a_text_of_long_reads_at_size(qc_mod, c_oracle):
         assert ctx.submit_fastq(text) == n_reads
         got = ctx.read_stats()
         tables = ctx.finalize()
+        _took(ctx, line_sums_from)
     _check(got, want)
     assert_tables_equal(tables, wt)
     assert int(tables["totals"][1]) == nb
+
+
+def test_a_text_of_short_reads_at_size(qc_mod, c_oracle, line_sums_from):
+    """0.25 GB of 500-base reads (the regime the one-pass kernels are for: BASELINE's FASTQ leg at a mean of 500), LF
+    and CRLF halves, every record and table against the host packer + C oracle; by its own choice the library takes the
+    one-pass kernels for the second text of a context (the first one tells it how long the lines are)."""
+    if "short" not in _BIG:
+        rng = np.random.default_rng(123)
+        lens = np.clip(np.rint(rng.lognormal(np.log(500) - 0.32, 0.8, 220_000)), 1, 60_000).astype(np.int64)
+        nb = int(lens.sum())
+        hb = rng.choice(np.frombuffer(b"ACGTACGTACGTN", np.uint8), nb).tobytes()
+        hq = rng.integers(33, 90, nb, dtype=np.uint8).tobytes()
+        off = np.concatenate([[0], np.cumsum(lens)])
+        half = len(lens) // 2
+        text = b"".join(b"@r%d runid=f read=%d ch=%d start_time=2018-06-03T%02d:%02d:00Z%s%s%s+%s%s%s" % (
+            i, i, 1 + i % 512, i % 24, i % 60, nl, hb[off[i]:off[i + 1]], nl, nl, hq[off[i]:off[i + 1]], nl)
+            for i in range(len(lens)) for nl in ((b"\n" if i < half else b"\r\n"),))
+        _BIG["short"] = (text, len(lens), nb, _host_path(qc_mod, c_oracle, text))
+    text, n_reads, nb, (p, want, wt) = _BIG["short"]
+    assert p["n_reads"] == n_reads and int(want["length"].sum()) == nb
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        assert ctx.submit_fastq(text) == n_reads
+        got = ctx.read_stats()
+        tables = ctx.finalize()
+        _took(ctx, line_sums_from)
+        _check(got, want)
+        assert_tables_equal(tables, wt)
+        ctx.reset()
+        assert ctx.submit_fastq(text) == n_reads         # again: now the context knows the lines are short
+        if line_sums_from == "auto":
+            assert ctx.path_count("fastq_one_pass") == 1
+        assert_tables_equal(ctx.finalize(), wt)
