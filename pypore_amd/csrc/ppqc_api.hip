@@ -698,14 +698,22 @@ constexpr int64_t kFastqNotesMinLine = 320;   // below: more than 25 line ends p
 // than the text once as well and do less arithmetic per byte; below, a region's lines outgrow its share of the point table.
 constexpr int64_t kFq1MinLine = 160, kFq1MaxLine = kFastqSumsMinLine;
 
-static void fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_records) {
+// lens_written: the kernels have left lens32 and raised the sort gate for these reads, as finalize_reads does
+static int fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_records, bool lens_written) {
+    if (lens_written && R) {
+        HIPCHK(hipEventRecord(c->ev_reads, c->stream));
+        ++c->reads_gen;
+    } else if (R) {
+        c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
+    }
     c->n_reads += R;
     c->state = 0;
-    c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
+    c->n50_early = false;
     c->pre_ok = false;
     c->cells_early = c->cells_done = c->cmh_on_host = false;
     c->bases_total += n;     // the text holds every base
     if (n_records) *n_records = R;
+    return PPQC_OK;
 }
 
 static int fastq_line_count_error(uint64_t n_lines) {
@@ -745,10 +753,9 @@ static int run_fastq_one_pass(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint
     if (R >= (1ull << 30)) return fail(PPQC_E_RANGE, "more than 2^30-1 records in one text");
     CHK(ensure_reads(c, c->n_reads + R));
     HIPCHK(launch_fq1_finalize(text, n, R, c->fq1, cpr, n_regions, c->ra, c->n_reads, c->lut_dev, c->qthr, mux,
-                               c->res_buf + c->res_words, s));
-    fastq_committed(c, R, n, n_records);
+                               c->res_buf + c->res_words, c->cfg.n_channels, c->res_buf + c->res_words + 8, s));
     *done = true;
-    return PPQC_OK;
+    return fastq_committed(c, R, n, n_records, true);
 }
 
 static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, uint64_t* n_records) {
@@ -827,8 +834,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     if (hdr_aux) HIPCHK(hipStreamWaitEvent(s, c->ev_hdr, 0));
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
                                  c->lut_dev, c->qthr, mux, c->res_buf + c->res_words, s, from_sums));
-    fastq_committed(c, R, n, n_records);
-    return PPQC_OK;
+    return fastq_committed(c, R, n, n_records, false);
 }
 
 int ppqc_submit_fastq_device(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, uint64_t* n_records) {

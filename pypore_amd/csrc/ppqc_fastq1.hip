@@ -15,16 +15,17 @@
 //                     A lane owns a contiguous 128-byte strip of each chunk (eight 16-byte loads at a stride of 128
 //                     bytes between lanes stream as fast as coalesced ones, tools/probes/strided_probe.hip), so the
 //                     prefix runs inside a lane and ONE set of wave scans per chunk joins the lanes.  The few vectors
-//                     that hold a newline are set aside in LDS and worked off together at the end of the chunk (the
-//                     partial sums in front of each newline: a masked second lookup), with the lanes packed.
+//                     that hold a newline are noted in LDS (the lane's running sums in front of them) and worked off
+//                     together at the end of the chunk, 64 at a time with the lanes packed: the vector is read again
+//                     (a cache hit) and the partial sums in front of each newline come from a masked second lookup.
 //   fq1_regions_kernel  exclusive prefix over the regions' totals (a single block), line count and flags to the host.
 //   fq1_finalize_kernel one thread per record: its five points -> lengths, stripped line ends, validation, the header
 //                     fields, the per-read arrays fastq_finalize_kernel writes.  It reads the text only for the title
 //                     and where a line end is not plain "\n" or "\r\n".
 //
 // What the pass cannot do it leaves to ppqc_fastq_gpu.hip (the host looks at the flags before anything is committed): a
-// chunk with more than kFq1Cap newline vectors or a region with more lines than its share of the point table (reads of
-// fewer than ~100 bases).  Results are bit-identical to that path and to the host packer + CSR path
+// region with more lines than its share of the point table (kFq1LinesPerChunk per chunk: reads of fewer than ~100 bases
+// throughout a region).  Results are bit-identical to that path and to the host packer + CSR path
 // (tests/test_gpu_fastq.py runs every text through all of them).
 #include "ppqc_fastq_dev.hpp"
 #include "ppqc_internal.hpp"
@@ -32,7 +33,7 @@
 namespace ppqc {
 
 constexpr int kFq1Vecs = 8;              // 16-byte vectors of a lane's strip
-constexpr int kFq1Cap = 64;              // newline vectors of one chunk the wave's buffer holds
+constexpr int kFq1Cap = 512;             // newline vectors of one chunk the wave's buffer holds: every vector of it
 constexpr int kF1Gcs = 55, kF1N = 58, kF1Odd = 61;   // three-bit counters above the 55 bits of an error sum of <= 7 bytes
 constexpr uint64_t kF1Err = (1ull << 55) - 1;
 constexpr uint64_t kM48 = (1ull << 48) - 1;
@@ -59,12 +60,18 @@ __device__ __forceinline__ F1Sums f1_sums(const uint4& x, const uint64_t* lut2) 
                         lut2[x.w >> 24];
     F1Sums s;
     s.err = (a0 & kF1Err) + (a1 & kF1Err) + (a2 & kF1Err);
-    auto widen = [](uint64_t a) {
-        const uint32_t c = (uint32_t)(a >> 55);
-        return (c & 7u) | ((c & 0x38u) << 5) | ((c & 0x1C0u) << 10);
-    };
-    s.gno = widen(a0) + widen(a1) + widen(a2);
+    // the three accumulators' counters side by side, nine bits each; a 24-bit multiply by 1 + 2^9 + 2^18 leaves the sum
+    // of a counter's three copies at bit 18 (no carry reaches it: two copies sum to 11 at most below it)
+    const uint32_t y = (uint32_t)(a0 >> 55) | ((uint32_t)(a1 >> 55) << 9) | ((uint32_t)(a2 >> 55) << 18);
+    const uint32_t g = (__umul24(y & 0x1C0E07u, 0x40201u) >> 18) & 31u;
+    const uint32_t nn = (__umul24((y >> 3) & 0x1C0E07u, 0x40201u) >> 18) & 31u;
+    const uint32_t o = (__umul24((y >> 6) & 0x1C0E07u, 0x40201u) >> 18) & 31u;
+    s.gno = g | (nn << 8) | (o << 16);
     return s;
+}
+__device__ __forceinline__ uint32_t nl_nomatch(uint32_t v) {   // bit 7 of every byte that is NOT '\n' (other bits: anything)
+    const uint32_t x = v ^ 0x0A0A0A0Au;
+    return ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
 }
 __device__ __forceinline__ uint32_t f1_bytesum(const uint4& x) {
     uint32_t q = __builtin_amdgcn_sad_u8(x.x, 0u, 0u);
@@ -109,9 +116,9 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
                                                        uint64_t* __restrict__ points, uint32_t cap_lines,
                                                        Fq1Region* __restrict__ regions) {
     __shared__ uint64_t lut2[256];
-    __shared__ uint4 bx[4][kFq1Cap];      // the newline vectors of the chunk ...
-    __shared__ uint4 br[4][kFq1Cap];      // ... the lane's running sums in front of each: error (2 words), gno, byte sum
-    __shared__ uint32_t bm[4][kFq1Cap];   // ... lane * 8 + vector | the lane's newlines in front of it << 16
+    // the newline vectors of the chunk: the lane's running sums in front of each (error in two words, gno) and
+    // byte sum (15 bits) | the lane's newlines in front of it << 15 (8 bits) | lane * 8 + vector << 23
+    __shared__ uint4 br[4][kFq1Cap];
     lut2[threadIdx.x] = lut2_entry(threadIdx.x, lut_g[threadIdx.x]);
     __syncthreads();
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -124,12 +131,18 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
     // the region's running totals (wave-uniform)
     uint32_t B_lines = 0, B_gcs = 0, B_n = 0, B_odd = 0;
     uint64_t B_qb = 0, B_a = 0, B_b = 0;   // error sum = B_a + B_b * 2^48, B_a < 2^48
-    bool dense = false, over = false;
+    bool over = false;
     for (uint64_t c = c0; c < c1; ++c) {
         const uint64_t cb = c * kNlChunk;
         uint4 vv[kFq1Vecs];
+        if (cb + kNlChunk <= n) {   // wave-uniform: all of the chunk lies in the text
 #pragma unroll
-        for (int j = 0; j < kFq1Vecs; ++j) vv[j] = f1_load(text, cb + (uint64_t)lane * 128 + (uint64_t)j * 16, n, ends_nl);
+            for (int j = 0; j < kFq1Vecs; ++j)
+                vv[j] = *reinterpret_cast<const uint4*>(text + cb + (uint64_t)lane * 128 + (uint64_t)j * 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kFq1Vecs; ++j) vv[j] = f1_load(text, cb + (uint64_t)lane * 128 + (uint64_t)j * 16, n, ends_nl);
+        }
         uint64_t r_err = 0;                       // the lane's running sums over its strip
         uint32_t r_gno = 0, r_qb = 0, r_nl = 0;
         uint32_t ne = 0;                          // newline vectors of the chunk so far (wave-uniform)
@@ -137,18 +150,17 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
         for (int j = 0; j < kFq1Vecs; ++j) {
             const uint4& x = vv[j];
             const F1Sums s = f1_sums(x, lut2);
-            const uint32_t m0 = nl_mask(x.x), m1 = nl_mask(x.y), m2 = nl_mask(x.z), m3 = nl_mask(x.w);
-            const uint32_t any = m0 | m1 | m2 | m3;
+            // t: bit 7 of a byte is clear iff the byte is '\n'; the four words folded before the test
+            const uint32_t t0 = nl_nomatch(x.x), t1 = nl_nomatch(x.y), t2 = nl_nomatch(x.z), t3 = nl_nomatch(x.w);
+            const uint32_t any = ~(t0 & t1 & t2 & t3) & 0x80808080u;
             const uint64_t ball = __ballot(any != 0);
             if (ball) {
                 const uint32_t at = ne + __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
-                if (any != 0 && at < (uint32_t)kFq1Cap) {
-                    bx[wib][at] = x;
-                    br[wib][at] = make_uint4((uint32_t)r_err, (uint32_t)(r_err >> 32), r_gno, r_qb);
-                    bm[wib][at] = (uint32_t)(lane * 8 + j) | (r_nl << 16);
-                }
+                if (any != 0)   // at < 512: a chunk has 512 vectors
+                    br[wib][at] = make_uint4((uint32_t)r_err, (uint32_t)(r_err >> 32), r_gno,
+                                             r_qb | (r_nl << 15) | ((uint32_t)(lane * 8 + j) << 23));
                 ne += (uint32_t)__popcll(ball);
-                r_nl += __popc((m0 >> 7) | (m1 >> 6) | (m2 >> 5) | (m3 >> 4));
+                r_nl += __popc(((~t0 & 0x80808080u) >> 7) | ((~t1 & 0x80808080u) >> 6) | ((~t2 & 0x80808080u) >> 5) | ((~t3 & 0x80808080u) >> 4));
             }
             r_err += s.err; r_gno += s.gno; r_qb += f1_bytesum(x);
         }
@@ -159,37 +171,54 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
         const uint32_t o4 = (uint32_t)r_err & 0x3FFFFFFu, o5 = (uint32_t)(r_err >> 26) & 0x3FFFFFFu, o6 = (uint32_t)(r_err >> 52);
         const uint32_t i1 = wave_scan_incl_u32(o1), i2 = wave_scan_incl_u32(o2), i3 = wave_scan_incl_u32(o3);
         const uint32_t i4 = wave_scan_incl_u32(o4), i5 = wave_scan_incl_u32(o5), i6 = wave_scan_incl_u32(o6);
-        if (ne > (uint32_t)kFq1Cap) dense = true;
-        const uint32_t nq = ne < (uint32_t)kFq1Cap ? ne : (uint32_t)kFq1Cap;
-        if (nq) {
-            // the newline vectors of the chunk, one per lane: lane q takes entry q
-            const bool live = (uint32_t)lane < nq;
+        for (uint32_t eb = 0; eb < ne; eb += 64) {
+            // the newline vectors of the chunk, one per lane, 64 at a time; the vector itself comes from the text again
+            // (it is in the cache: the wave has just read it)
+            const bool live = eb + (uint32_t)lane < ne;
             uint4 x = make_uint4(0, 0, 0, 0), rr = make_uint4(0, 0, 0, 0);
-            uint32_t meta = 0;
-            if (live) { x = bx[wib][lane]; rr = br[wib][lane]; meta = bm[wib][lane]; }
-            const int src = (int)((meta & 0xFFFFu) >> 3);   // the lane that owns the vector
+            if (live) rr = br[wib][eb + lane];
+            const uint32_t vi = rr.w >> 23;
+            if (live) x = f1_load(text, cb + (uint64_t)vi * 16, n, ends_nl);
+            const int src = (int)(vi >> 3);   // the lane that owns the vector
             const uint32_t e1 = (uint32_t)__shfl((int)(i1 - o1), src), e2 = (uint32_t)__shfl((int)(i2 - o2), src);
             const uint32_t e3 = (uint32_t)__shfl((int)(i3 - o3), src), e4 = (uint32_t)__shfl((int)(i4 - o4), src);
             const uint32_t e5 = (uint32_t)__shfl((int)(i5 - o5), src), e6 = (uint32_t)__shfl((int)(i6 - o6), src);
-            const uint32_t vi = meta & 0xFFFFu;
             const uint32_t gcs0 = B_gcs + (e1 & 0xFFFFu) + (rr.z & 0xFFu), n0 = B_n + (e1 >> 16) + ((rr.z >> 8) & 0xFFu);
             const uint32_t odd0 = B_odd + (e3 & 0xFFFFu) + ((rr.z >> 16) & 0xFFu);
-            uint32_t line = B_lines + (e3 >> 16) + (meta >> 16);
-            const uint64_t qb0 = B_qb + e2 + rr.w;
+            uint32_t line = B_lines + (e3 >> 16) + ((rr.w >> 15) & 0xFFu);
+            const uint64_t qb0 = B_qb + e2 + (rr.w & 0x7FFFu);
             const uint64_t sum0 = B_a + e4 + ((uint64_t)e5 << 26) + (((uint64_t)rr.y << 32) | rr.x);   // < 2^61
             const uint64_t bb0 = B_b + ((uint64_t)e6 << 4);
             const uint32_t rel0 = (uint32_t)(c - c0) * kNlChunk + vi * 16;
             const uint64_t gpos0 = cb + (uint64_t)vi * 16;
             uint32_t bits = live ? vec_nl_bits(x, 16) : 0u;
+            // sums of the vector's bytes in front of the newline at hand: from a masked lookup of the whole vector for
+            // its first newline, for a further one a few bytes on ("\n+\n") by adding those bytes
+            int pb = -1;
+            uint64_t perr = 0;
+            uint32_t pgcs = 0, pn = 0, podd = 0, pqb = 0;
             while (__ballot(bits != 0) != 0) {
                 if (bits != 0) {
                     const int b = __ffs((int)bits) - 1;
                     bits &= bits - 1;
-                    uint32_t m[4];
-                    range_masks(0, b, m);
-                    const uint4 xm = make_uint4(x.x & m[0], x.y & m[1], x.z & m[2], x.w & m[3]);
-                    const F1Sums p = f1_sums(xm, lut2);   // the 16 - b zeroed bytes count as odd
-                    const uint32_t podd = ((p.gno >> 16) & 0xFFu) - (uint32_t)(16 - b);
+                    if (pb < 0 || b - pb > 4) {
+                        uint32_t m[4];
+                        range_masks(0, b, m);
+                        const uint4 xm = make_uint4(x.x & m[0], x.y & m[1], x.z & m[2], x.w & m[3]);
+                        const F1Sums p = f1_sums(xm, lut2);   // the 16 - b zeroed bytes count as odd
+                        perr = p.err; pgcs = p.gno & 0xFFu; pn = (p.gno >> 8) & 0xFFu;
+                        podd = ((p.gno >> 16) & 0xFFu) - (uint32_t)(16 - b);
+                        pqb = f1_bytesum(xm);
+                    } else {
+                        podd += 1; pqb += '\n';   // the newline at pb
+                        for (int t = pb + 1; t < b; ++t) {
+                            const uint32_t c = f1_byte(x, t);
+                            const uint64_t v = lut2[c];
+                            perr += v & kF1Err; pgcs += (uint32_t)(v >> kF1Gcs) & 1u; pn += (uint32_t)(v >> kF1N) & 1u;
+                            podd += (uint32_t)(v >> kF1Odd) & 1u; pqb += c;
+                        }
+                    }
+                    pb = b;
                     const uint64_t gpos = gpos0 + (uint64_t)b;
                     // the bytes around the line end
                     uint32_t prev = 'x', next = 0;
@@ -199,10 +228,10 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
                     uint32_t tw = 0;
                     if (is_space((uint8_t)prev)) tw = (prev == '\r' && b >= 2 && !is_space((uint8_t)f1_byte(x, b - 2))) ? 1u : 3u;
                     const uint32_t cls = next == '@' ? 1u : (next == '+' ? 2u : 0u);
-                    const uint64_t S = sum0 + p.err;
+                    const uint64_t S = sum0 + perr;
                     const uint64_t q0 = (S & kM48) | ((uint64_t)cls << 48) | ((uint64_t)tw << 50);
-                    const uint64_t q1 = ((bb0 + (S >> 48)) & 0xFFFFFFFFull) | ((qb0 + f1_bytesum(xm)) << 32);
-                    const uint64_t q2 = (uint64_t)(gcs0 + (p.gno & 0xFFu)) | ((uint64_t)(n0 + ((p.gno >> 8) & 0xFFu)) << 24);
+                    const uint64_t q1 = ((bb0 + (S >> 48)) & 0xFFFFFFFFull) | ((qb0 + pqb) << 32);
+                    const uint64_t q2 = (uint64_t)(gcs0 + pgcs) | ((uint64_t)(n0 + pn) << 24);
                     const uint64_t q3 = (uint64_t)(odd0 + podd) | ((uint64_t)(rel0 + (uint32_t)b) << 24);
                     if (line < cap_lines) {
                         ulonglong2* o = reinterpret_cast<ulonglong2*>(out + (uint64_t)line * 4);
@@ -228,42 +257,225 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
     if (lane == 0) {
         Fq1Region r;
         r.lines = B_lines; r.gcs = B_gcs; r.n = B_n; r.odd = B_odd; r.qb = B_qb; r.err_a = B_a; r.err_b = B_b;
-        r.flags = (dense ? 1u : 0u) | (any_over || B_lines > cap_lines ? 2u : 0u);
+        r.flags = any_over || B_lines > cap_lines ? 2u : 0u;
         regions[region] = r;
     }
 }
 
 // Single block: regions[k] becomes the exclusive prefix of the regions' totals; head = {lines of the text, OR of the
-// flags}, also to the pinned words the host waits for.
-__global__ __launch_bounds__(256) void fq1_regions_kernel(Fq1Region* __restrict__ regions, uint64_t n_regions,
-                                                          uint64_t* __restrict__ head, uint64_t* __restrict__ host_out) {
-    __shared__ Fq1Region part[256];
+// flags}, also to the pinned words the host waits for.  Every thread adds up a run of regions, a Hillis-Steele scan in
+// LDS joins the 1024 runs field by field (the error sum's low part as a plain sum: 2^15 regions of 2^48 at most).
+constexpr int kRegThreads = 1024;
+__global__ __launch_bounds__(kRegThreads) void fq1_regions_kernel(Fq1Region* __restrict__ regions, uint64_t n_regions,
+                                                                  uint64_t* __restrict__ head, uint64_t* __restrict__ host_out) {
+    __shared__ uint64_t sh[8][kRegThreads];
     const uint32_t t = threadIdx.x;
-    const uint64_t seg = (n_regions + 255) / 256;
-    const uint64_t b = t * seg, e = b + seg < n_regions ? b + seg : n_regions;
-    Fq1Region s = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto add = [](Fq1Region& a, const Fq1Region& v) {
-        a.lines += v.lines; a.gcs += v.gcs; a.n += v.n; a.odd += v.odd; a.qb += v.qb;
-        const uint64_t S = a.err_a + v.err_a;
-        a.err_a = S & kM48; a.err_b += v.err_b + (S >> 48);
-        a.flags |= v.flags;
-    };
-    for (uint64_t i = b; i < e; ++i) add(s, regions[i]);
-    part[t] = s;
+    const uint64_t seg = (n_regions + kRegThreads - 1) / kRegThreads;
+    const uint64_t b = t * seg < n_regions ? t * seg : n_regions, e = b + seg < n_regions ? b + seg : n_regions;
+    uint64_t tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // lines, gcs, n, odd, qb, err_a, err_b, flags
+    for (uint64_t i = b; i < e; ++i) {
+        const Fq1Region v = regions[i];
+        tot[0] += v.lines; tot[1] += v.gcs; tot[2] += v.n; tot[3] += v.odd; tot[4] += v.qb; tot[5] += v.err_a;
+        tot[6] += v.err_b; tot[7] |= v.flags;
+    }
+    uint64_t run[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) { run[f] = tot[f]; sh[f][t] = tot[f]; }
     __syncthreads();
-    if (t == 0) {
-        Fq1Region run = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < 256; ++i) { const Fq1Region v = part[i]; part[i] = run; add(run, v); }
-        head[0] = run.lines; head[1] = run.flags;
+    for (uint32_t o = 1; o < (uint32_t)kRegThreads; o <<= 1) {   // all eight fields in step
+        uint64_t x[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) x[f] = t >= o ? sh[f][t - o] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < 8; ++f) { run[f] = f == 7 ? (run[f] | x[f]) : run[f] + x[f]; sh[f][t] = run[f]; }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int f = 0; f < 7; ++f) run[f] -= tot[f];   // exclusive (the flags: inclusive, only the last thread's are used)
+    if (t == kRegThreads - 1) {
+        head[0] = run[0] + tot[0]; head[1] = run[7];
         if (host_out) {
-            host_out[0] = run.lines; host_out[1] = run.flags;
+            host_out[0] = run[0] + tot[0]; host_out[1] = run[7];
             __threadfence_system();
         }
     }
-    __syncthreads();
-    Fq1Region run = part[t];
-    run.flags = 0;
-    for (uint64_t i = b; i < e; ++i) { const Fq1Region v = regions[i]; regions[i] = run; add(run, v); }
+    for (uint64_t i = b; i < e; ++i) {
+        const Fq1Region v = regions[i];
+        Fq1Region o;
+        o.lines = run[0]; o.gcs = run[1]; o.n = run[2]; o.odd = run[3]; o.qb = run[4];
+        o.err_a = run[5] & kM48; o.err_b = run[6] + (run[5] >> 48); o.flags = 0;
+        regions[i] = o;
+        run[0] += v.lines; run[1] += v.gcs; run[2] += v.n; run[3] += v.odd; run[4] += v.qb; run[5] += v.err_a; run[6] += v.err_b;
+    }
+}
+
+// ---- the title's fields --------------------------------------------------------------------------------------------
+// ch= and start_time= of the title [a, e) ('@' at a, line end stripped or not), by the rules of the host packer
+// (ppqc_fastq.cpp: a key counts where it stands at the start of the title or behind a blank or tab, and only its first
+// occurrence; "ch=" is followed by decimal digits, "start_time=" by YYYY-MM-DD(T or blank)HH:MM:SS) -- the same
+// fields HeaderScan finds byte by byte.  Here the title is searched by words for '=' (a handful per title), and only
+// the bytes around each are looked at: some 500 instructions per title instead of 3000.  n_cr: its '\r' bytes.
+__device__ __forceinline__ uint32_t byte_eq_mask(uint32_t v, uint32_t k4) {   // high bit of each byte that equals the byte of k4
+    const uint32_t x = v ^ k4;
+    const uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu;
+    return ~t;
+}
+__device__ __forceinline__ uint32_t eq_mask(uint32_t v) { return byte_eq_mask(v, 0x3D3D3D3Du); }
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t x) {   // high bit of each byte of x that is zero (exact)
+    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+struct TitleFields {
+    uint32_t ch;
+    int64_t time;
+    uint32_t n_cr;
+};
+__device__ __forceinline__ bool f1_blank(uint32_t c) { return c == ' ' || c == '\t'; }
+// An '=' at position P of the text whose left neighbour is 'h' or 'e': the 32 bytes text[P - 12 .. P + 20) in two
+// unaligned loads (cache hits: the title has just been streamed), every byte of them at a fixed place.
+struct KeyWindow {
+    uint32_t w[8];
+    __device__ __forceinline__ uint32_t at(int i) const { return (w[(i + 12) >> 2] >> (8 * ((i + 12) & 3))) & 0xffu; }   // text[P + i]
+    __device__ __forceinline__ void load(const uint8_t* __restrict__ text, uint64_t P) { __builtin_memcpy(w, text + P - 12, 32); }
+};
+// "ch=" with its '=' at P: true if it is the key (at the title's start t0 or behind a blank); *ch = its digits
+__device__ __forceinline__ bool title_ch(const uint8_t* __restrict__ text, const KeyWindow& k, uint64_t t0, uint64_t e,
+                                         uint64_t P, uint32_t* ch) {
+    if (!(k.at(-2) == 'c' && P >= t0 + 2 && (P - 2 == t0 || f1_blank(k.at(-3))))) return false;
+    uint32_t c = 0;
+    bool open = true;     // digits so far
+#pragma unroll
+    for (int i = 1; i < 20; ++i) {
+        const uint32_t d = k.at(i) - '0';
+        open = open && d <= 9u && P + (uint64_t)i < e;
+        if (open) c = c * 10u + d;
+    }
+    if (open)             // twenty digits and more: the host packer goes on (and wraps around)
+        for (uint64_t p = P + 20; p < e; ++p) {
+            const uint32_t d = (uint32_t)text[p] - '0';
+            if (d > 9u) break;
+            c = c * 10u + d;
+        }
+    *ch = c;
+    return true;
+}
+// the same for "start_time="; *time stays INT64_MIN if what follows is no time
+__device__ __forceinline__ bool title_time(const KeyWindow& k, uint64_t t0, uint64_t e, uint64_t P, int64_t* time) {
+    if (!(P >= t0 + 10 && (P - 10 == t0 || f1_blank(k.at(-11))))) return false;
+    const char key[] = "start_tim";
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) same = same && k.at(i - 10) == (uint32_t)(uint8_t)key[i];
+    if (!same) return false;
+    if (P + 20 > e) return true;
+    uint32_t f[6] = {0, 0, 0, 0, 0, 0};   // year, month, day, hour, minute, second
+    bool good = true;
+#pragma unroll
+    for (int i = 0; i < 19; ++i) {
+        const uint32_t c = k.at(1 + i);
+        const bool sep = i == 4 || i == 7 || i == 10 || i == 13 || i == 16;
+        if (sep) good = good && (i == 10 ? (c == 'T' || c == ' ') : (i < 10 ? c == '-' : c == ':'));
+        else {
+            const uint32_t d = c - '0';
+            good = good && d <= 9u;
+            const int fi = i < 4 ? 0 : (i - 2) / 3;   // 5,6 -> 1; 8,9 -> 2; 11,12 -> 3; 14,15 -> 4; 17,18 -> 5
+            f[fi] = f[fi] * 10u + d;
+        }
+    }
+    if (good && f[1] >= 1 && f[1] <= 12 && f[2] >= 1 && f[2] <= 31)
+        *time = days_from_civil((int64_t)f[0], f[1], f[2]) * 86400 + (int64_t)f[3] * 3600 + (int64_t)f[4] * 60 + (int64_t)f[5];
+    return true;
+}
+// Two steps, so that the lanes of a wave stay together: first the whole title by words, noting where "h=" and "e="
+// stand (up to four each, in order); then the candidates, every lane its first, its second, ...  The loads come in
+// batches -- four granules of the title at a time, one batch ahead; the windows of the first two candidates together --
+// because the kernel is a chain of memory latencies and little else.
+__device__ __forceinline__ TitleFields parse_title(const uint8_t* __restrict__ text, uint64_t n, uint64_t a, uint64_t e) {
+    TitleFields out{0, INT64_MIN, 0};
+    if (e <= a + 1) return out;
+    bool slow = a < 12 || e + 20 > n || e - a > 60000;   // the key windows would leave the text (the first and the last record at most)
+    uint64_t hc = 0, ec = 0;     // title indices of the candidates, 16 bits each
+    uint32_t nh = 0, ne = 0;
+    bool many = false;           // two candidates in one word, or more than four in the title
+    if (!slow) {
+        const int len = (int)(e - a);
+        const uintptr_t base = (uintptr_t)(text + a), endp = (uintptr_t)(text + e);
+        uintptr_t ga = base & ~(uintptr_t)15;
+        int k = -(int)(base & 15u);           // index in the title of the granule's first byte
+        uint32_t last_w = 0, any_cr = 0;      // the word in front of the one looked at; '\r' bytes seen
+        uint4 cur[4], nxt[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cur[i] = make_uint4(0, 0, 0, 0);
+            if (ga + 16 * i < endp) cur[i] = *reinterpret_cast<const uint4*>(ga + 16 * i);
+        }
+        while (ga < endp) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                nxt[i] = make_uint4(0, 0, 0, 0);
+                if (ga + 64 + 16 * i < endp) nxt[i] = *reinterpret_cast<const uint4*>(ga + 64 + 16 * i);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // the granule's bytes outside the title (the '@' at index 0 too) become zero: they match nothing
+                const int kg = k + 16 * i;
+                const int x0 = 1 - kg < 0 ? 0 : (1 - kg > 16 ? 16 : 1 - kg), x1 = len - kg < 0 ? 0 : (len - kg > 16 ? 16 : len - kg);
+                uint32_t m[4];
+                range_masks(x0, x1 < x0 ? x0 : x1, m);
+                const uint32_t w[4] = {cur[i].x & m[0], cur[i].y & m[1], cur[i].z & m[2], cur[i].w & m[3]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // byte b is a candidate when it is '=' and the byte in front of it 'h' (or 'e'): one zero-byte test
+                    // of (w ^ "====") | (the stream shifted by a byte ^ "hhhh")
+                    const uint32_t before = __builtin_amdgcn_alignbit(w[q], last_w, 24);   // byte b: the byte in front of byte b of w
+                    last_w = w[q];
+                    const uint32_t xe = w[q] ^ 0x3D3D3D3Du;
+                    const uint32_t c1 = zero_bytes(xe | (before ^ 0x68686868u)), c2 = zero_bytes(xe | (before ^ 0x65656565u));
+                    any_cr |= zero_bytes(w[q] ^ 0x0D0D0D0Du);
+                    if (c1) {
+                        if (nh < 4) hc |= (uint64_t)(uint32_t)(kg + 4 * q + ((__ffs((int)c1) - 1) >> 3)) << (16 * nh);
+                        ++nh;
+                        many = many || (c1 & (c1 - 1)) != 0;
+                    }
+                    if (c2) {
+                        if (ne < 4) ec |= (uint64_t)(uint32_t)(kg + 4 * q + ((__ffs((int)c2) - 1) >> 3)) << (16 * ne);
+                        ++ne;
+                        many = many || (c2 & (c2 - 1)) != 0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+            ga += 64; k += 64;
+        }
+        if (any_cr)
+            for (uint64_t p = a + 1; p < e; ++p) out.n_cr += text[p] == '\r';
+        bool ch_done = false, st_done = false;
+        KeyWindow kh, ke;   // the first candidate of each key, loaded together
+        if (nh) kh.load(text, a + (hc & 0xFFFFu));
+        if (ne) ke.load(text, a + (ec & 0xFFFFu));
+        if (nh) ch_done = title_ch(text, kh, a + 1, e, a + (hc & 0xFFFFu), &out.ch);
+        if (ne) st_done = title_time(ke, a + 1, e, a + (ec & 0xFFFFu), &out.time);
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if ((uint32_t)i < nh && !ch_done) {
+                kh.load(text, a + ((hc >> (16 * i)) & 0xFFFFu));
+                ch_done = title_ch(text, kh, a + 1, e, a + ((hc >> (16 * i)) & 0xFFFFu), &out.ch);
+            }
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if ((uint32_t)i < ne && !st_done) {
+                ke.load(text, a + ((ec >> (16 * i)) & 0xFFFFu));
+                st_done = title_time(ke, a + 1, e, a + ((ec >> (16 * i)) & 0xFFFFu), &out.time);
+            }
+        slow = many || (nh > 4 && !ch_done) || (ne > 4 && !st_done);   // candidates that were not noted
+    }
+    if (slow) {   // byte by byte
+        const HeaderFields hf = scan_header<false, false>(text, a, e);
+        out.ch = hf.ch; out.time = hf.time; out.n_cr = 0;
+        for (uint64_t p = a; p < e; ++p) out.n_cr += text[p] == '\r';
+    }
+    return out;
 }
 
 // ---- records from points -------------------------------------------------------------------------------------------
@@ -271,14 +483,20 @@ struct F1Point {
     uint64_t pos, gcs, n, odd, qb, ea, eb;   // absolute position of the line end; prefixes of the text in front of it
     uint32_t cls, tw;
 };
-// the end of line k of the text; reg: a region whose first line is at or before k (moved forward as needed)
+__device__ __forceinline__ F1Point f1_decode(const ulonglong2& a, const ulonglong2& b, const Fq1Region& R, uint64_t reg,
+                                             uint64_t region_bytes);
+// the end of line k of the text; reg: a region whose first line is at or before k (moved forward as needed), R: the
+// prefix of region held (the record's five points lie in one region, seldom in two)
 __device__ __forceinline__ F1Point f1_point(const uint64_t* __restrict__ points, const Fq1Region* __restrict__ rb,
-                                            uint64_t n_regions, uint64_t& reg, uint64_t k, uint32_t cap_lines,
-                                            uint64_t region_bytes) {
+                                            uint64_t n_regions, uint64_t& reg, Fq1Region& R, uint64_t& held, uint64_t k,
+                                            uint32_t cap_lines, uint64_t region_bytes) {
     while (reg + 1 < n_regions && rb[reg + 1].lines <= k) ++reg;
-    const Fq1Region R = rb[reg];
+    if (held != reg) { R = rb[reg]; held = reg; }
     const ulonglong2* q = reinterpret_cast<const ulonglong2*>(points + (reg * (uint64_t)cap_lines + (k - R.lines)) * 4);
-    const ulonglong2 a = q[0], b = q[1];
+    return f1_decode(q[0], q[1], R, reg, region_bytes);
+}
+__device__ __forceinline__ F1Point f1_decode(const ulonglong2& a, const ulonglong2& b, const Fq1Region& R, uint64_t reg,
+                                             uint64_t region_bytes) {
     F1Point p;
     p.pos = reg * region_bytes + ((b.y >> 24) & 0xFFFFFFull);
     p.gcs = R.gcs + (b.x & 0xFFFFFFull); p.n = R.n + ((b.x >> 24) & 0xFFFFFFull); p.odd = R.odd + (b.y & 0xFFFFFFull);
@@ -335,35 +553,64 @@ __global__ __launch_bounds__(256) void fq1_finalize_kernel(const uint8_t* __rest
                                                            const Fq1Region* __restrict__ rb, uint64_t n_regions,
                                                            uint32_t cap_lines, uint64_t region_bytes, ReadArrays ra,
                                                            uint64_t read_base, const uint64_t* __restrict__ lut_g,
-                                                           QThr thr, uint8_t mux, uint64_t* __restrict__ errors) {
-    __shared__ unsigned int s_mis, s_bad;
-    if (threadIdx.x == 0) { s_mis = 0; s_bad = 0; }
+                                                           QThr thr, uint8_t mux, uint64_t* __restrict__ errors,
+                                                           uint32_t n_channels, uint64_t* __restrict__ gate,
+                                                           float reg_per_line) {
+    __shared__ unsigned int s_mis, s_bad, s_max;
+    if (threadIdx.x == 0) { s_mis = 0; s_bad = 0; s_max = 0; }
     __syncthreads();
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t misplaced = 0, bad = 0;
     if (r < n_records) {
         const uint64_t g = read_base + r;
-        // the region of the record's first point: binary search over the regions' first lines
+        // the region of the record's first point: lines are spread evenly over a text, so the region in proportion is the
+        // right one or next to it (a binary search is thirteen dependent loads)
         const uint64_t k0 = r ? 4 * r - 1 : 0;
-        uint64_t lo = 0, hi = n_regions;   // rb[lo].lines <= k0 < rb[hi].lines (rb[n_regions] = +inf)
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (rb[mid].lines <= k0) lo = mid; else hi = mid;
+        uint64_t reg = (uint64_t)((float)k0 * reg_per_line);
+        if (reg >= n_regions) reg = n_regions - 1;
+        Fq1Region R = rb[reg];
+        uint64_t next_first = reg + 1 < n_regions ? rb[reg + 1].lines : ~0ull;
+        if (R.lines > k0 || (next_first <= k0 && reg + 2 < n_regions && rb[reg + 2].lines <= k0)) {
+            // not there and not next to it (a text whose line lengths drift): binary search over the regions' first lines
+            uint64_t lo = 0, hi = n_regions;   // rb[lo].lines <= k0 < rb[hi].lines (rb[n_regions] = +inf)
+            while (hi - lo > 1) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (rb[mid].lines <= k0) lo = mid; else hi = mid;
+            }
+            reg = lo;
+            R = rb[reg];
+            next_first = reg + 1 < n_regions ? rb[reg + 1].lines : ~0ull;
         }
-        uint64_t reg = lo;
+        uint64_t held = reg;
         F1Point P[5];
-        if (r) P[0] = f1_point(points, rb, n_regions, reg, 4 * r - 1, cap_lines, region_bytes);
-        else {   // in front of the text: as if a newline ended at position -1
-            P[0].pos = ~0ull; P[0].gcs = 0; P[0].n = 0; P[0].odd = ~0ull; P[0].qb = (uint64_t)(-10ll); P[0].ea = 0; P[0].eb = 0;
-            P[0].cls = text[0] == '@' ? 1u : 0u; P[0].tw = 0;
-        }
+        if (r != 0 && R.lines <= k0 && 4 * r + 3 < next_first) {
+            // the five points lie in one region (nearly always): their ten loads go out together
+            const ulonglong2* q = reinterpret_cast<const ulonglong2*>(points + (reg * (uint64_t)cap_lines + (k0 - R.lines)) * 4);
+            ulonglong2 v[10];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) P[t + 1] = f1_point(points, rb, n_regions, reg, 4 * r + t, cap_lines, region_bytes);
+            for (int t = 0; t < 10; ++t) v[t] = q[t];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) P[t] = f1_decode(v[2 * t], v[2 * t + 1], R, reg, region_bytes);
+        } else {
+            if (r) P[0] = f1_point(points, rb, n_regions, reg, R, held, 4 * r - 1, cap_lines, region_bytes);
+            else {   // in front of the text: as if a newline ended at position -1
+                P[0].pos = ~0ull; P[0].gcs = 0; P[0].n = 0; P[0].odd = ~0ull; P[0].qb = (uint64_t)(-10ll); P[0].ea = 0; P[0].eb = 0;
+                P[0].cls = text[0] == '@' ? 1u : 0u; P[0].tw = 0;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) P[t + 1] = f1_point(points, rb, n_regions, reg, R, held, 4 * r + t, cap_lines, region_bytes);
+        }
         F1Line H = f1_line(P[0], P[1]), S = f1_line(P[1], P[2]), U = f1_line(P[2], P[3]), Q = f1_line(P[3], P[4]);
         // title: '@', and no '\r' but at its end (a bare CR is a line end to SeqIO); the fields
-        const HeaderFields hf = scan_header<false, true>(text, H.a, H.e + (H.e < n ? 1 : 0));
+        const TitleFields hf = parse_title(text, n, H.a, H.e - (P[1].tw == 1 ? 1 : 0));   // without the '\r' of a plain "\r\n"
         bool ok = P[0].cls == 1 && P[2].cls == 2;
-        if (hf.cr_inside) ++misplaced;
+        if (hf.n_cr != 0) {   // is any of them inside?
+            uint64_t he = H.e;
+            while (he > H.a && is_space(text[he - 1])) --he;
+            bool inside = false;
+            for (uint64_t p = H.a; p < he; ++p) inside = inside || text[p] == '\r';
+            if (inside) ++misplaced;
+        }
         // '+' line: alone, or followed by the title again
         {
             uint64_t e = U.e;
@@ -398,9 +645,14 @@ __global__ __launch_bounds__(256) void fq1_finalize_kernel(const uint8_t* __rest
         ra.err_hi[g] = hi32; ra.err_lo[g] = lo32;
         ra.mean_q[g] = mq;
         ra.flags[g] = flags;
-        ra.channel[g] = ok ? hf.ch : 0u;
+        const uint32_t ch = ok ? hf.ch : 0u;
+        ra.channel[g] = ch;
         ra.mux[g] = mux;
         ra.time[g] = ok ? hf.time : INT64_MIN;
+        // the sort key and the sort gate, as finalize_reads leaves them: the sort + N50 chain may start behind this kernel
+        const uint32_t key = (ch >= 1 && ch <= n_channels) ? (uint32_t)Lr : 0u;
+        ra.lens32[g] = key;
+        if (key) atomicMax(&s_max, key);
     }
     misplaced = wave_sum_u32(misplaced);
     bad = wave_sum_u32(bad);
@@ -412,6 +664,7 @@ __global__ __launch_bounds__(256) void fq1_finalize_kernel(const uint8_t* __rest
     if (threadIdx.x == 0) {
         if (s_mis) atomicAdd((unsigned long long*)&errors[6], (unsigned long long)s_mis);
         if (s_bad) atomicAdd((unsigned long long*)&errors[3], (unsigned long long)s_bad);
+        if (s_max) atomicOr((unsigned long long*)&gate[blockIdx.x & (kGateWords - 1)], (unsigned long long)s_max);
     }
 }
 
@@ -432,17 +685,18 @@ hipError_t launch_fq1_scan(const uint8_t* text, uint64_t n, const Fq1Scratch& f,
     const uint64_t n_chunks = fq1_chunks(n);
     hipLaunchKernelGGL(fq1_scan_kernel, dim3((unsigned)((n_regions + 3) / 4)), dim3(256), 0, s, text, n, n_chunks, cpr, lut_dev,
                        f.points, cpr * kFq1LinesPerChunk, f.regions);
-    hipLaunchKernelGGL(fq1_regions_kernel, dim3(1), dim3(256), 0, s, f.regions, n_regions, f.head, host_out);
+    hipLaunchKernelGGL(fq1_regions_kernel, dim3(1), dim3(kRegThreads), 0, s, f.regions, n_regions, f.head, host_out);
     return hipGetLastError();
 }
 
 hipError_t launch_fq1_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const Fq1Scratch& f, uint32_t cpr,
                                uint64_t n_regions, ReadArrays ra, uint64_t read_base, const uint64_t* lut_dev,
-                               const QThr& thr, uint8_t mux, uint64_t* errors, hipStream_t s) {
+                               const QThr& thr, uint8_t mux, uint64_t* errors, uint32_t n_channels, uint64_t* gate,
+                               hipStream_t s) {
     if (n_records == 0) return hipSuccess;
     hipLaunchKernelGGL(fq1_finalize_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n, n_records,
                        f.points, f.regions, n_regions, cpr * kFq1LinesPerChunk, (uint64_t)cpr * kNlChunk, ra, read_base,
-                       lut_dev, thr, mux, errors);
+                       lut_dev, thr, mux, errors, n_channels, gate, (float)((double)n_regions / (4.0 * (double)n_records)));
     return hipGetLastError();
 }
 

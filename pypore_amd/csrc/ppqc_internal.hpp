@@ -224,7 +224,7 @@ struct Fq1Region { uint64_t lines, gcs, n, odd, qb, err_a, err_b, flags; };   //
 struct Fq1Scratch {
     uint64_t* points;      // 4 words per line end, kFq1LinesPerChunk per chunk
     Fq1Region* regions;
-    uint64_t* head;        // lines of the text, flags (1: a chunk with too many newline vectors, 2: a region with too many lines)
+    uint64_t* head;        // lines of the text, flags (2: a region with more lines than its share of the point table)
 };
 uint64_t fq1_chunks(uint64_t n);
 void fq1_shape(uint64_t n, int want_regions, uint32_t* cpr, uint64_t* n_regions);
@@ -232,7 +232,8 @@ hipError_t launch_fq1_scan(const uint8_t* text, uint64_t n, const Fq1Scratch& f,
                            const uint64_t* lut_dev, uint64_t* host_out, hipStream_t s);
 hipError_t launch_fq1_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const Fq1Scratch& f, uint32_t cpr,
                                uint64_t n_regions, ReadArrays ra, uint64_t read_base, const uint64_t* lut_dev,
-                               const QThr& thr, uint8_t mux, uint64_t* errors, hipStream_t s);
+                               const QThr& thr, uint8_t mux, uint64_t* errors, uint32_t n_channels, uint64_t* gate,
+                               hipStream_t s);   // also writes lens32 and raises the sort gate, like finalize_reads
 
 hipError_t launch_synth(uint8_t* bases, uint8_t* quals, uint64_t first, uint64_t n, uint64_t seed, hipStream_t s);
 
