@@ -24,6 +24,7 @@ constexpr uint64_t kStaticScratchBytes = kStaticSortMaxKeys * 4 + kStaticSortCou
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 constexpr int kMaxDevices = 64;
 static unsigned char* g_static_scratch[kMaxDevices];   // per device; written once under g_static_mu
+
 static std::mutex g_static_mu;
 
 static thread_local std::string g_err;
@@ -44,6 +45,42 @@ int ppqc_set_error(int code, const std::string& msg) { return fail(code, msg); }
         int rc_ = (expr);             \
         if (rc_ != PPQC_OK) return rc_; \
     } while (0)
+
+// The four streams of a context (main, auxiliary, two copy streams) come from a per-device pool and go back to it when
+// the context is destroyed: a process that creates contexts by the hundred (a test run, a service with a context per
+// request) would otherwise keep creating and destroying hardware queues, and on this stack a process that has been
+// through a few hundred of them -- or three processes with a few each on one GPU -- was seen to stall for good on a wait
+// between two of its streams (tests hanging in hipEventSynchronize / hipStreamSynchronize with nothing left to run).
+// The pool is as large as the largest number of contexts alive at once and is never freed.
+struct StreamSet { hipStream_t own = nullptr, aux = nullptr, copy[2] = {nullptr, nullptr}; };
+static std::mutex g_streams_mu;
+static std::vector<StreamSet> g_streams[kMaxDevices];
+static int take_streams(int device, StreamSet* out) {
+    {
+        std::lock_guard<std::mutex> lock(g_streams_mu);
+        if (device >= 0 && device < kMaxDevices && !g_streams[device].empty()) {
+            *out = g_streams[device].back();
+            g_streams[device].pop_back();
+            return PPQC_OK;
+        }
+    }
+    StreamSet s;
+    HIPCHK(hipStreamCreateWithFlags(&s.own, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&s.aux, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&s.copy[i], hipStreamNonBlocking));
+    *out = s;
+    return PPQC_OK;
+}
+static void give_streams(int device, const StreamSet& s) {   // the streams are idle (the caller has synchronised the device)
+    if (!s.own) return;
+    if (device >= 0 && device < kMaxDevices) {
+        std::lock_guard<std::mutex> lock(g_streams_mu);
+        g_streams[device].push_back(s);
+        return;
+    }
+    (void)hipStreamDestroy(s.own); (void)hipStreamDestroy(s.aux);
+    for (int i = 0; i < 2; ++i) (void)hipStreamDestroy(s.copy[i]);
+}
 
 namespace {
 
@@ -370,10 +407,13 @@ static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    {
+        StreamSet ss;
+        CHK(take_streams(device, &ss));
+        c->own_stream = ss.own; c->aux = ss.aux; c->copy[0] = ss.copy[0]; c->copy[1] = ss.copy[1];
+    }
     c->stream = c->own_stream;
     for (int i = 0; i < 2; ++i) {
-        HIPCHK(hipStreamCreateWithFlags(&c->copy[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->slot[i].copied, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->slot[i].done, hipEventDisableTiming));
     }
@@ -386,13 +426,6 @@ static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_hdr, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_cells, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_cmhcopy, hipEventDisableTiming));
-    {   // The auxiliary stream's kernels are few and small and run BESIDE the per-read kernel, whose grid of tens of thousands
-        // of workgroups otherwise keeps every wave slot it frees for itself (dense_kernel: four waves of 128 registers per
-        // SIMD): at the highest priority the dispatcher places their workgroups first whenever a slot opens.
-        int least = 0, greatest = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, greatest));
-    }
     HIPCHK(hipEventCreate(&c->ev_join));
     HIPCHK(hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->ev_reads));
@@ -501,20 +534,22 @@ int ppqc_destroy(ppqc_ctx* c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_reads) (void)hipEventDestroy(c->ev_reads);
-    if (c->aux) (void)hipStreamDestroy(c->aux);
     for (int i = 0; i < 2; ++i) {
         Slot& s = c->slot[i];
         void* sp[] = {s.bases, s.quals, s.mux, s.ff, s.offsets, s.channel, s.time};
         for (void* p : sp) if (p) (void)hipFree(p);
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.done) (void)hipEventDestroy(s.done);
-        if (c->copy[i]) (void)hipStreamDestroy(c->copy[i]);
     }
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     hipEvent_t evs[] = {c->ev_t0, c->ev_t1, c->ev_s0, c->ev_s1};
     for (auto e : evs) if (e) (void)hipEventDestroy(e);
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    {
+        StreamSet ss;
+        ss.own = c->own_stream; ss.aux = c->aux; ss.copy[0] = c->copy[0]; ss.copy[1] = c->copy[1];
+        give_streams(c->device, ss);
+    }
     delete c;
     return PPQC_OK;
 }
@@ -698,19 +733,35 @@ constexpr int64_t kFastqNotesMinLine = 320;   // below: more than 25 line ends p
 // than the text once as well and do less arithmetic per byte; below, a region's lines outgrow its share of the point table.
 constexpr int64_t kFq1MinLine = 160, kFq1MaxLine = kFastqSumsMinLine;
 
-// lens_written: the kernels have left lens32 and raised the sort gate for these reads, as finalize_reads does
-static int fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_records, bool lens_written) {
+// lens_written: the kernels have left lens32 and raised the sort gate for these reads, as finalize_reads does; pre: and
+// their index-only results (extremes, hours; cells: the packed cells too), as extremes_kernel<true> does for a CSR batch
+static int fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_records, bool lens_written, bool pre, bool cells) {
     if (lens_written && R) {
+        if (pre) {
+            // hours and cells are there (fq1_finalize_kernel); the extremes over the run's arrays, in line on the main
+            // stream (nothing to run beside), and the auxiliary stream, where a CSR batch's index kernel runs and
+            // whatever needs its results is ordered, falls in behind
+            BatchView v{nullptr, nullptr, nullptr, R, n, nullptr, kDefaultTileShift, nullptr, nullptr, nullptr};
+            HIPCHK(launch_batch_extremes(v, c->n_reads, c->ra, c->tp, c->max_buf, c->min_buf, c->tminmax,
+                                         c->res_buf + c->res_words + 4, c->maxlen_host + 4, nullptr,
+                                         c->res_buf + c->res_words + 8, c->stream));
+            HIPCHK(hipEventRecord(c->ev_pre, c->stream));
+            HIPCHK(hipStreamWaitEvent(c->aux, c->ev_pre, 0));
+            if (cells) c->cells_dirty = true;
+            c->last_b = nullptr;   // no per-read kernel whose end the sort chain could start at: behind ev_reads
+            c->last_dense_alone = false;
+        }
         HIPCHK(hipEventRecord(c->ev_reads, c->stream));
         ++c->reads_gen;
     } else if (R) {
         c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
     }
+    if (R && !cells) c->cells_early = false;
     c->n_reads += R;
     c->state = 0;
     c->n50_early = false;
-    c->pre_ok = false;
-    c->cells_early = c->cells_done = c->cmh_on_host = false;
+    if (R && !pre) c->pre_ok = false;
+    c->cells_done = c->cmh_on_host = false;
     c->bases_total += n;     // the text holds every base
     if (n_records) *n_records = R;
     return PPQC_OK;
@@ -752,10 +803,15 @@ static int run_fastq_one_pass(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint
     const uint64_t R = n_lines / 4;
     if (R >= (1ull << 30)) return fail(PPQC_E_RANGE, "more than 2^30-1 records in one text");
     CHK(ensure_reads(c, c->n_reads + R));
+    // The index-only results of these reads with the same kernel, as a CSR batch leaves them when it is submitted
+    // (run_batch): the finalize then needs no extremes kernel and the tables no cell atomics.
+    const bool pre = c->pre_ok && c->res_clean && c->cfg.time_mode == 0 && c->tn.pre != 0;
+    const bool cells = pre && c->cells_early && cmh_packable(c->n_reads + R, c->bases_total + n);
+    Fq1Index ix{pre ? 1 : 0, c->tp, cells ? c->sum_buf + c->tp.lay.off_cmh_bases : nullptr};
     HIPCHK(launch_fq1_finalize(text, n, R, c->fq1, cpr, n_regions, c->ra, c->n_reads, c->lut_dev, c->qthr, mux,
-                               c->res_buf + c->res_words, c->cfg.n_channels, c->res_buf + c->res_words + 8, s));
+                               c->res_buf + c->res_words, c->cfg.n_channels, c->res_buf + c->res_words + 8, ix, s));
     *done = true;
-    return fastq_committed(c, R, n, n_records, true);
+    return fastq_committed(c, R, n, n_records, true, pre, cells);
 }
 
 static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, uint64_t* n_records) {
@@ -834,7 +890,7 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
     if (hdr_aux) HIPCHK(hipStreamWaitEvent(s, c->ev_hdr, 0));
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
                                  c->lut_dev, c->qthr, mux, c->res_buf + c->res_words, s, from_sums));
-    return fastq_committed(c, R, n, n_records, false);
+    return fastq_committed(c, R, n, n_records, false, false, false);
 }
 
 int ppqc_submit_fastq_device(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, uint64_t* n_records) {

@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void fq1_finalize_kernel(const uint8_t* __rest
                                                            uint64_t read_base, const uint64_t* __restrict__ lut_g,
                                                            QThr thr, uint8_t mux, uint64_t* __restrict__ errors,
                                                            uint32_t n_channels, uint64_t* __restrict__ gate,
-                                                           float reg_per_line) {
+                                                           float reg_per_line, Fq1Index ix) {
     __shared__ unsigned int s_mis, s_bad, s_max;
     if (threadIdx.x == 0) { s_mis = 0; s_bad = 0; s_max = 0; }
     __syncthreads();
@@ -653,6 +653,7 @@ __global__ __launch_bounds__(256) void fq1_finalize_kernel(const uint8_t* __rest
         const uint32_t key = (ch >= 1 && ch <= n_channels) ? (uint32_t)Lr : 0u;
         ra.lens32[g] = key;
         if (key) atomicMax(&s_max, key);
+        if (ix.on) ra.hour[g] = index_cell(ch, (uint32_t)Lr, ok ? hf.time : INT64_MIN, mux, ix.tp, ix.cells);   // time_mode 0
     }
     misplaced = wave_sum_u32(misplaced);
     bad = wave_sum_u32(bad);
@@ -692,11 +693,12 @@ hipError_t launch_fq1_scan(const uint8_t* text, uint64_t n, const Fq1Scratch& f,
 hipError_t launch_fq1_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const Fq1Scratch& f, uint32_t cpr,
                                uint64_t n_regions, ReadArrays ra, uint64_t read_base, const uint64_t* lut_dev,
                                const QThr& thr, uint8_t mux, uint64_t* errors, uint32_t n_channels, uint64_t* gate,
-                               hipStream_t s) {
+                               const Fq1Index& ix, hipStream_t s) {
     if (n_records == 0) return hipSuccess;
-    hipLaunchKernelGGL(fq1_finalize_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n, n_records,
-                       f.points, f.regions, n_regions, cpr * kFq1LinesPerChunk, (uint64_t)cpr * kNlChunk, ra, read_base,
-                       lut_dev, thr, mux, errors, n_channels, gate, (float)((double)n_regions / (4.0 * (double)n_records)));
+    hipLaunchKernelGGL(fq1_finalize_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n,
+                       n_records, f.points, f.regions, n_regions, cpr * kFq1LinesPerChunk, (uint64_t)cpr * kNlChunk, ra,
+                       read_base, lut_dev, thr, mux, errors, n_channels, gate,
+                       (float)((double)n_regions / (4.0 * (double)n_records)), ix);
     return hipGetLastError();
 }
 

@@ -230,10 +230,19 @@ uint64_t fq1_chunks(uint64_t n);
 void fq1_shape(uint64_t n, int want_regions, uint32_t* cpr, uint64_t* n_regions);
 hipError_t launch_fq1_scan(const uint8_t* text, uint64_t n, const Fq1Scratch& f, uint32_t cpr, uint64_t n_regions,
                            const uint64_t* lut_dev, uint64_t* host_out, hipStream_t s);
+// Part of the index-only results of the text's reads from the same kernel (on != 0): their hour bins and, with cells,
+// their packed (channel, mux, hour) cells -- the million-odd atomics that are best issued from a kernel busy with
+// something else.  The extremes follow in extremes_kernel<true> over the run's arrays (launch_batch_extremes, offsets
+// == nullptr), which then leaves hours and cells alone.
+struct Fq1Index {
+    int on;
+    TableParams tp;
+    uint64_t* cells;   // nullptr: no (channel, mux, hour) cells
+};
 hipError_t launch_fq1_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const Fq1Scratch& f, uint32_t cpr,
                                uint64_t n_regions, ReadArrays ra, uint64_t read_base, const uint64_t* lut_dev,
                                const QThr& thr, uint8_t mux, uint64_t* errors, uint32_t n_channels, uint64_t* gate,
-                               hipStream_t s);   // also writes lens32 and raises the sort gate, like finalize_reads
+                               const Fq1Index& ix, hipStream_t s);   // also writes lens32 and raises the sort gate, like finalize_reads
 
 hipError_t launch_synth(uint8_t* bases, uint8_t* quals, uint64_t first, uint64_t n, uint64_t seed, hipStream_t s);
 
@@ -353,6 +362,26 @@ __device__ __forceinline__ uint8_t quality_flags(uint64_t L, uint64_t H, uint64_
     return (uint8_t)(fl | ((qbin + 1) << 4));
 }
 
+// ---- index-only results of a read: what extremes_kernel (ppqc_tables.hip) and fq1_finalize_kernel share -------------
+constexpr int kCmhShift = 40;                      // packed (channel, mux, hour) cell: bases below, reads above this bit
+constexpr uint32_t kExtremesLdsChannels = 8000;    // per-channel extremes are privatised in LDS up to this many channels
+__device__ __forceinline__ int64_t floordiv64(int64_t a, int64_t b) {
+    int64_t q = a / b;
+    return ((a % b != 0) && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+// The hour bin of a read (time_mode 0; -1: none: no good channel, no start time -- INT64_MIN, a FASTQ header without
+// start_time= --, or outside the bins) and, with `cells`, its packed (channel, mux, hour) cell.
+__device__ __forceinline__ int32_t index_cell(uint32_t ch, uint32_t L, int64_t t, uint32_t m, const TableParams& tp, uint64_t* cells) {
+    int32_t hour = -1;
+    if (ch >= 1 && ch <= tp.lay.n_channels && t != INT64_MIN && tp.time_mode == 0) {
+        const int64_t h = floordiv64(t - tp.ref_time_s + tp.tz_offset_s, (int64_t)tp.bin_seconds);
+        hour = (h >= 0 && h < (int64_t)tp.lay.n_time_bins) ? (int32_t)h : -1;
+    }
+    if (cells != nullptr && hour >= 0 && m >= 1 && m <= tp.lay.n_mux)
+        atomicAdd((unsigned long long*)&cells[((uint64_t)(ch - 1) * tp.lay.n_mux + (m - 1)) * tp.lay.n_time_bins + (uint32_t)hour],
+                  (1ull << kCmhShift) | (unsigned long long)L);
+    return hour;
+}
 // ---- byte classification shared by the per-read kernels and the FASTQ text kernels ------------------------------
 struct Acc {
     uint32_t gcs, n, qb;

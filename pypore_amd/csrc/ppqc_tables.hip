@@ -8,10 +8,6 @@
 
 namespace ppqc {
 
-__device__ __forceinline__ int64_t floordiv64(int64_t a, int64_t b) {
-    int64_t q = a / b;
-    return ((a % b != 0) && ((a < 0) != (b < 0))) ? q - 1 : q;
-}
 // hour of day of (t - ref + tz): int(time.strftime('%H', time.localtime(t - ref)))  (lib/fast5_reader.py:118)
 __device__ __forceinline__ int32_t hour_of_day(int64_t t, const TableParams& tp) {
     int64_t h = floordiv64(t - tp.ref_time_s + tp.tz_offset_s, (int64_t)tp.bin_seconds) % 24;
@@ -34,7 +30,6 @@ __device__ __forceinline__ int32_t hour_of_day(int64_t t, const TableParams& tp)
 // splits the cells; the host checks at finalize time that no field can have overflowed, cmh_packable).  These atomics
 // execute at the memory side at about 20 per ns for the whole chip, whoever issues them: issued here they cost the
 // per-read kernel beside them nothing, issued by tables_kernel they were two thirds of the step's tail at 4 * 10^6 reads.
-constexpr int kCmhShift = 40;
 template <bool BATCH>
 __global__ __launch_bounds__(1024) void extremes_kernel(BatchView b, uint64_t base, ReadArrays ra, uint64_t n,
                                                        TableParams tp, uint64_t* max_buf, uint64_t* min_buf,
@@ -56,7 +51,12 @@ __global__ __launch_bounds__(1024) void extremes_kernel(BatchView b, uint64_t ba
         uint32_t ch, L;
         int64_t t;
         uint64_t g = i;
-        if (BATCH) {
+        const bool from_run = BATCH && b.offsets == nullptr;   // the reads of a FASTQ text: in the run's arrays already, with
+                                                               // hours and cells (fq1_finalize_kernel)
+        if (from_run) {
+            g = base + i;
+            ch = ra.channel[g]; L = ra.len[g]; t = ra.time[g];
+        } else if (BATCH) {
             g = base + i;
             ch = b.channel[i];
             t = b.time[i];
@@ -93,9 +93,9 @@ __global__ __launch_bounds__(1024) void extremes_kernel(BatchView b, uint64_t ba
                 }
             }
         }
-        if (tp.time_mode == 0) ra.hour[g] = hour;
+        if (tp.time_mode == 0 && !from_run) ra.hour[g] = hour;
         uint32_t m = 0;
-        if (BATCH) {   // the batch's metadata into the run's arrays (finalize_reads leaves them to this kernel)
+        if (BATCH && !from_run) {   // the batch's metadata into the run's arrays (finalize_reads leaves them to this kernel)
             m = b.mux[i];
             ra.channel[g] = ch; ra.mux[g] = (uint8_t)m; ra.time[g] = t;
         }
@@ -464,7 +464,6 @@ static inline unsigned grid_for(uint64_t n, unsigned cap) {
 }
 
 // 8 B of dynamic LDS per channel beside the kernel's 32 B of static words: 8000 channels stay under 64 KiB
-constexpr uint32_t kExtremesLdsChannels = 8000;
 
 hipError_t launch_extremes(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* max_buf, uint64_t* min_buf,
                            int64_t* tminmax, bool write_lens, hipStream_t s) {
@@ -490,7 +489,8 @@ hipError_t launch_batch_extremes(const BatchView& b, uint64_t base, ReadArrays r
     // nothing (2048 waves of 8 reads each cost config 2 about 15 us of tile-kernel time).
     // ... while a batch of many short reads needs a wider grid, or this kernel outlasts the per-read kernel (8 * 10^6 reads of
     // 150 bases: 1.4 ms on 64 workgroups beside 0.7 ms of dense_kernel): 16 384 reads per workgroup, 64 to 512 workgroups.
-    uint64_t wg = b.n_reads / 16384;
+    // b.offsets == nullptr (the reads of a FASTQ text, from the run's arrays): nothing runs beside it, a wider grid
+    uint64_t wg = b.n_reads / (b.offsets ? 16384 : 4096);
     wg = wg < 64 ? 64 : (wg > 512 ? 512 : wg);
     hipLaunchKernelGGL(extremes_kernel<true>, dim3(grid_for(b.n_reads, (unsigned)wg)),
                        dim3(256), (size_t)nchL * 8, s, b, base, ra, b.n_reads, tp, max_buf,

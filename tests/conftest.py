@@ -23,3 +23,16 @@ def c_oracle():
 def qc_mod():
     from pypore_amd import qc
     return qc
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _release_torch_cache(request):
+    """A module that used torch for device memory (the 100 GB resident job of test_gpu_fullsize) leaves it in torch's
+    caching allocator, out of reach of the library's own hipMalloc in the modules that follow: hand it back."""
+    yield
+    if "fullsize" in request.module.__name__ and "torch" in sys.modules:
+        import gc
+        import torch
+        if torch.cuda.is_available():
+            gc.collect()
+            torch.cuda.empty_cache()
