@@ -737,6 +737,9 @@ constexpr int64_t kFq1MinLine = 160, kFq1MaxLine = kFastqSumsMinLine;
 // their index-only results (extremes, hours; cells: the packed cells too), as extremes_kernel<true> does for a CSR batch
 static int fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_records, bool lens_written, bool pre, bool cells) {
     if (lens_written && R) {
+        // lens32 and the gate are complete behind the text's last kernel: the sort + N50 chain may start here
+        HIPCHK(hipEventRecord(c->ev_reads, c->stream));
+        ++c->reads_gen;
         if (pre) {
             // hours and cells are there (fq1_finalize_kernel); the extremes over the run's arrays, in line on the main
             // stream (nothing to run beside), and the auxiliary stream, where a CSR batch's index kernel runs and
@@ -751,8 +754,6 @@ static int fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_reco
             c->last_b = nullptr;   // no per-read kernel whose end the sort chain could start at: behind ev_reads
             c->last_dense_alone = false;
         }
-        HIPCHK(hipEventRecord(c->ev_reads, c->stream));
-        ++c->reads_gen;
     } else if (R) {
         c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
     }

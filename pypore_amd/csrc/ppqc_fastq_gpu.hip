@@ -25,23 +25,32 @@ namespace ppqc {
 
 // high bit of each byte set where a QUALITY byte is invalid: outside '!'..'~' and not ASCII white space (line ends and
 // trailing blanks are stripped, not judged)
-__device__ __forceinline__ uint32_t badq_mask(uint32_t x) {
+__device__ __forceinline__ uint32_t badq_mask(uint32_t x, uint32_t* ws_out = nullptr) {
     const uint32_t H = 0x80808080u, hi = x & H, lo7 = x & 0x7F7F7F7Fu;
     const uint32_t ge9 = (lo7 + 0x77777777u) & H, ge14 = (lo7 + 0x72727272u) & H, ge32 = (lo7 + 0x60606060u) & H;
     const uint32_t ge33 = (lo7 + 0x5F5F5F5Fu) & H, ge127 = (lo7 + 0x01010101u) & H;
     const uint32_t invalid = hi | (~ge33 & H) | ge127;
     const uint32_t ws = ((ge9 & ~ge14) | (ge32 & ~ge33)) & ~hi;
+    if (ws_out) *ws_out = ws;
     return invalid & ~ws;
 }
-__device__ __forceinline__ uint32_t vec_badq_bits(const uint4& v, int valid) {
+// *n_ws (optional): the white-space bytes among the first `valid`, a by-product of the same masks
+__device__ __forceinline__ uint32_t vec_badq_bits(const uint4& v, int valid, uint32_t* n_ws = nullptr) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    uint32_t bits = 0;
+    uint32_t bits = 0, wsb = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t m = badq_mask(w[k]);
+        uint32_t ws = 0;
+        const uint32_t m = badq_mask(w[k], &ws);
         bits |= (((m >> 7) & 1u) | ((m >> 14) & 2u) | ((m >> 21) & 4u) | ((m >> 28) & 8u)) << (4 * k);
+        wsb |= (ws >> 7) << k;   // byte b of word k at bit 8 b + k: only their number matters
     }
-    if (valid < 16) bits &= valid <= 0 ? 0u : ((1u << valid) - 1u);
+    if (valid < 16) {
+        bits &= valid <= 0 ? 0u : ((1u << valid) - 1u);
+        if (n_ws) *n_ws = vec_ws_count(v, valid);   // the end of the text: once per text
+    } else if (n_ws) {
+        *n_ws = __popc(wsb);
+    }
     return bits;
 }
 
@@ -127,8 +136,10 @@ __global__ __launch_bounds__(256) void nl_scan_kernel(const uint8_t* __restrict_
         if (oddv) {
             const uint64_t rem = n - pos;
             bits = vec_nl_bits(v, rem < 16 ? (int)rem : 16);
-            if (NOTES) bad = vec_badq_bits(v, rem < 16 ? (int)rem : 16);
-            wsn += vec_ws_count(v, rem < 16 ? (int)rem : 16);
+            uint32_t nws = 0;
+            if (NOTES) bad = vec_badq_bits(v, rem < 16 ? (int)rem : 16, &nws);
+            else nws = vec_ws_count(v, rem < 16 ? (int)rem : 16);
+            wsn += nws;
         }
         cnt += __popc(bits);
         const uint64_t odd = NOTES ? __ballot((bits | bad) != 0) : 0ull;

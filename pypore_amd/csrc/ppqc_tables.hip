@@ -71,7 +71,7 @@ __global__ __launch_bounds__(1024) void extremes_kernel(BatchView b, uint64_t ba
             t = ra.time[i];
         }
         const bool good = ch >= 1 && ch <= nch;
-        if (write_lens) ra.lens32[g] = good ? L : 0;   // else finalize_reads left it (and a sort may be reading it)
+        if (write_lens && !from_run) ra.lens32[g] = good ? L : 0;   // else finalize_reads left it (and a sort may be reading it)
         int32_t hour = -1;
         if (good) {
             lmax = L > lmax ? L : lmax;
