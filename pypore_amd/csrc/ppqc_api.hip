@@ -208,6 +208,7 @@ struct ppqc_ctx {
     // ppqc_reset left it and nothing the hours depend on changes: the finalize then needs no extremes kernel, and the
     // sort + N50 chain, which needs only lens32, runs beside the tile kernel as well.
     bool pre_ok = false;    // every batch since ppqc_reset went that way
+    bool index_on_main = false;   // ... the newest of them (a one-pass FASTQ text) in line on the main stream, not on the auxiliary one
     bool pre_run = false;   // ... and the finalize in progress relies on it (set by ppqc_finalize_extremes)
     bool n50_early = false; // ppqc_n50_select_early has left the N50 of the run's reads (no batch since)
     hipEvent_t ev_pre = nullptr;   // behind the newest of those kernels (auxiliary stream)
@@ -568,6 +569,7 @@ int ppqc_reset(ppqc_ctx* c) {
     c->n50 = 0;
     c->lens_early = true;
     c->pre_ok = true;
+    c->index_on_main = false;
     c->pre_run = false;
     c->n50_early = false;
     c->bases_total = 0;
@@ -626,6 +628,7 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     c->cells_done = c->cmh_on_host = false;
     HIPCHK(launch_finalize_reads(v, c->ra, base, c->head, c->tail, c->qthr,
                                  c->res_buf + c->res_words, c->cfg.n_channels, c->res_buf + c->res_words + 8, !pre, s));
+    if (pre) c->index_on_main = false;
     if (pre) {
         // Enqueued behind the batch's kernels in host order (every call in front of the tile kernel's launch delays its
         // start) and ordered on the device behind the batch's start event, i.e. behind whatever produced the index on
@@ -742,14 +745,13 @@ static int fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_reco
         ++c->reads_gen;
         if (pre) {
             // hours and cells are there (fq1_finalize_kernel); the extremes over the run's arrays, in line on the main
-            // stream (nothing to run beside), and the auxiliary stream, where a CSR batch's index kernel runs and
-            // whatever needs its results is ordered, falls in behind
+            // stream (nothing to run beside)
             BatchView v{nullptr, nullptr, nullptr, R, n, nullptr, kDefaultTileShift, nullptr, nullptr, nullptr};
             HIPCHK(launch_batch_extremes(v, c->n_reads, c->ra, c->tp, c->max_buf, c->min_buf, c->tminmax,
                                          c->res_buf + c->res_words + 4, c->maxlen_host + 4, nullptr,
                                          c->res_buf + c->res_words + 8, c->stream));
             HIPCHK(hipEventRecord(c->ev_pre, c->stream));
-            HIPCHK(hipStreamWaitEvent(c->aux, c->ev_pre, 0));
+            c->index_on_main = true;   // whoever takes these results on the auxiliary stream waits for ev_pre (finalize_impl)
             if (cells) c->cells_dirty = true;
             c->last_b = nullptr;   // no per-read kernel whose end the sort chain could start at: behind ev_reads
             c->last_dense_alone = false;
@@ -1258,7 +1260,9 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     // need are enqueued.  lens32 has been there since the batches were submitted, but the chain still waits for the end
     // of finalize_reads: run beside the tile kernel its ten launches cost that kernel more time (3 %: every wave
     // resident beside it displaces one of its own) than they take behind it, beside the tables kernel.
-    const bool pre = local && c->pre_run && ss != s;
+    // (not behind a one-pass FASTQ text: its extremes end just in front of this call, the host would wait for them with
+    // nothing enqueued behind; the chain starts behind the text's last per-read kernel, gated on the device)
+    const bool pre = local && c->pre_run && ss != s && !c->index_on_main;
     // pre: the keys come from the batches' index kernels, so the chain does not wait for finalize_reads either: it starts
     // when the per-read kernel ends and runs beside finalize_reads and the tables
     // ... and beside the per-read kernel itself, right behind the index kernels, when that kernel is dense_kernel alone:
@@ -1360,8 +1364,11 @@ static int finalize_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
     // and copy the region (13.8 MB at 3000 x 4 x 72, the bulk of the result buffer) to the host mirror on a copy stream --
     // all of it beside the per-read kernel, which this call usually finds running.
     if (c->pre_run && c->cells_early && !c->cells_done) {
-        CHK(cells_unpack_on(c, c->aux));
-        CHK(cells_to_host_on(c, c->aux, c->copy[1]));
+        // (a one-pass FASTQ text left them on the main stream: there, and the auxiliary stream stays free for the sort
+        // chain, which can start behind the text's last per-read kernel)
+        hipStream_t us = c->index_on_main ? c->stream : c->aux;
+        CHK(cells_unpack_on(c, us));
+        CHK(cells_to_host_on(c, us, c->copy[1]));
     }
     CHK(ppqc_finalize_tables(c));
     CHK(finalize_n50_impl(c, nullptr, 0, true));
