@@ -538,7 +538,10 @@ def h2d_leg(a, torch, off, ch, mux, t, d_bases, d_quals, cfg):
     return {"gbases_per_s": round(nb / dt / 1e9, 2), "h2d_GBps": round((2 * nb + 21 * r) / dt / 1e9, 2),
             "sample": "first %d reads (%.2f Gbases) in %d batches of %d reads from pinned host memory, two staging "
                       "slots, tables + N50 included, %d passes" % (r, nb / 1e9, len(batches), a.batch_reads, passes),
-            "totals_ok": bool(ok)}
+            "totals_ok": bool(ok),
+            "what": "a bounded sample of BASELINE config 5 (end to end incl. H2D): the fixed tail of a step weighs on so "
+                    "short a run; the config-5 figure proper is `bench.py --stream` over the whole workload (DESIGN.md "
+                    "section 6 quotes both)"}
 
 
 def stream_mode(a, ctx, torch, off, ch, mux, t, d_bases, d_quals, n_bytes, R):

@@ -34,6 +34,7 @@ namespace ppqc {
 
 constexpr int kFq1Vecs = 8;              // 16-byte vectors of a lane's strip
 constexpr int kFq1Cap = 512;             // newline vectors of one chunk the wave's buffer holds: every vector of it
+constexpr int kFq1Keep = 48;             // ... of which the first few keep their 16 bytes in LDS as well (500-base reads: 28 per chunk)
 constexpr int kF1Gcs = 55, kF1N = 58, kF1Odd = 61;   // three-bit counters above the 55 bits of an error sum of <= 7 bytes
 constexpr uint64_t kF1Err = (1ull << 55) - 1;
 constexpr uint64_t kM48 = (1ull << 48) - 1;
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
     // the newline vectors of the chunk: the lane's running sums in front of each (error in two words, gno) and
     // byte sum (15 bits) | the lane's newlines in front of it << 15 (8 bits) | lane * 8 + vector << 23
     __shared__ uint4 br[4][kFq1Cap];
+    __shared__ uint4 bx[4][kFq1Keep];   // the first kFq1Keep of those vectors themselves (the others are read again)
     lut2[threadIdx.x] = lut2_entry(threadIdx.x, lut_g[threadIdx.x]);
     __syncthreads();
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -156,9 +158,11 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
             const uint64_t ball = __ballot(any != 0);
             if (ball) {
                 const uint32_t at = ne + __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
-                if (any != 0)   // at < 512: a chunk has 512 vectors
+                if (any != 0) {   // at < 512: a chunk has 512 vectors
                     br[wib][at] = make_uint4((uint32_t)r_err, (uint32_t)(r_err >> 32), r_gno,
                                              r_qb | (r_nl << 15) | ((uint32_t)(lane * 8 + j) << 23));
+                    if (at < (uint32_t)kFq1Keep) bx[wib][at] = x;
+                }
                 ne += (uint32_t)__popcll(ball);
                 r_nl += __popc(((~t0 & 0x80808080u) >> 7) | ((~t1 & 0x80808080u) >> 6) | ((~t2 & 0x80808080u) >> 5) | ((~t3 & 0x80808080u) >> 4));
             }
@@ -172,13 +176,15 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
         const uint32_t i1 = wave_scan_incl_u32(o1), i2 = wave_scan_incl_u32(o2), i3 = wave_scan_incl_u32(o3);
         const uint32_t i4 = wave_scan_incl_u32(o4), i5 = wave_scan_incl_u32(o5), i6 = wave_scan_incl_u32(o6);
         for (uint32_t eb = 0; eb < ne; eb += 64) {
-            // the newline vectors of the chunk, one per lane, 64 at a time; the vector itself comes from the text again
-            // (it is in the cache: the wave has just read it)
+            // the newline vectors of the chunk, one per lane, 64 at a time
             const bool live = eb + (uint32_t)lane < ne;
             uint4 x = make_uint4(0, 0, 0, 0), rr = make_uint4(0, 0, 0, 0);
             if (live) rr = br[wib][eb + lane];
             const uint32_t vi = rr.w >> 23;
-            if (live) x = f1_load(text, cb + (uint64_t)vi * 16, n, ends_nl);
+            if (live) {
+                if (eb + (uint32_t)lane < (uint32_t)kFq1Keep) x = bx[wib][eb + lane];
+                else x = f1_load(text, cb + (uint64_t)vi * 16, n, ends_nl);   // a cache hit, mostly: the wave has just read it
+            }
             const int src = (int)(vi >> 3);   // the lane that owns the vector
             const uint32_t e1 = (uint32_t)__shfl((int)(i1 - o1), src), e2 = (uint32_t)__shfl((int)(i2 - o2), src);
             const uint32_t e3 = (uint32_t)__shfl((int)(i3 - o3), src), e4 = (uint32_t)__shfl((int)(i4 - o4), src);

@@ -53,7 +53,7 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from pypore_amd import build
     sha = build.source_hash()   # the sources the profiled library was built from (run from the same tree)
-    ks = glob.glob(src + "/kt/**/*kernel_stats.csv", recursive=True)
+    ks = sorted(glob.glob(src + "/kt/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime, reverse=True)
     if ks:
         shutil.copy(ks[0], prefix + "_kernel_stats.csv")
     line = None
@@ -62,7 +62,7 @@ def main():
             if l.startswith("{"):
                 line = json.loads(l)
         if line is not None:
-            if alg is None:
+            if alg is None and "roofline" in line:
                 alg = line["roofline"]["bytes_per_launch"]
             json.dump(line, open(prefix + "_bench_line.json", "w"), indent=1)
     fetch, write = pmc_means(src + "/fetch", "FETCH_SIZE"), pmc_means(src + "/write", "WRITE_SIZE")
@@ -72,6 +72,30 @@ def main():
         res["tile_kernel_traffic_bytes_per_launch"] = {"fetch_raw": fr, "fetch_corrected_x2_gfx950": 2 * fr, "write": wr,
                                                        "total": 2 * fr + wr, "algorithmic": alg,
                                                        "kernels": [k[:60] for k in fetch if any(p in k for p in PER_READ)]}
+    # FASTQ legs (bench.py --fastq): the whole step's traffic, every kernel's mean x dispatches over the number of steps
+    # (= dispatches of the pass that reads the text: fq1_scan_kernel or nl_scan_kernel); FETCH_SIZE is doubled for the
+    # kernels that stream the text with 16-byte loads (the gfx950 correction), taken as it is for the others
+    if line is not None and "results" in line and any("fq1_scan_kernel" in k or "nl_scan_kernel" in k for k in fetch):
+        one_pass = any("fq1_scan_kernel" in k for k in fetch)
+        general = ("nl_", "line_sum_kernel", "fastq_header_kernel", "fastq_finalize_kernel", "tile_kernel", "dense_kernel")
+        streaming = ("fq1_scan_kernel", "nl_scan_kernel", "nl_fill_kernel", "tile_kernel", "dense_kernel", "line_sum_kernel")
+
+        def step_bytes(means, counter_steps):
+            # A context's first text (a warm-up step) goes through the general path whatever its lines: with one-pass
+            # kernels in the trace those kernels are left out, the one-pass kernels count once per step, the kernels both
+            # kinds of step share by their dispatches over all steps of the run.
+            tot = 0.0
+            for k, v in means.items():
+                if "synth" in k or (one_pass and any(p in k for p in general)):
+                    continue
+                per_step = 1.0 if (one_pass and "fq1_" in k) else v["dispatches"] / counter_steps
+                tot += v["mean_KB"] * 1024 * per_step * (2 if (means is fetch and any(p in k for p in streaming)) else 1)
+            return tot
+
+        pmc_steps = 3   # tools/profile_round.sh: --steps 2 --warmup 1 in the counter passes
+        res["fastq_step_traffic_bytes"] = {"fetch_corrected": step_bytes(fetch, pmc_steps), "write": step_bytes(write, pmc_steps),
+                                           "path": "one pass (ppqc_fastq1.hip)" if one_pass else "general (ppqc_fastq_gpu.hip)",
+                                           "workload": line["config"]["workload"]}
     res["csrc_sha16"] = sha
     json.dump(res, open(prefix + "_pmc_hbm.json", "w"), indent=1)
     print(json.dumps(res.get("tile_kernel_traffic_bytes_per_launch"), indent=1))
@@ -79,14 +103,16 @@ def main():
     if sq:
         out = {"csrc_sha16": sha, "unit": "per-launch mean", "kernels": {}}
         for k, d in sq.items():
-            if any(p in k for p in PER_READ) or "tables_kernel" in k:
+            if any(p in k for p in PER_READ) or "tables_kernel" in k or "fq1_" in k or "nl_scan" in k:
                 out["kernels"][k[:80]] = {c: v[1] / v[0] for c, v in d.items()}
                 out["kernels"][k[:80]]["dispatches"] = max(v[0] for v in d.values())
         json.dump(out, open(prefix + "_pmc_sq.json", "w"), indent=1)
     if ks:
         print(open(ks[0]).read()[:2500])
-    if line:
+    if line and "roofline" in line:
         print(json.dumps(line["roofline"]))
+    if "fastq_step_traffic_bytes" in res:
+        print(json.dumps(res["fastq_step_traffic_bytes"]))
 
 
 if __name__ == "__main__":
