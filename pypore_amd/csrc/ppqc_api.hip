@@ -208,7 +208,7 @@ struct ppqc_ctx {
     // ppqc_reset left it and nothing the hours depend on changes: the finalize then needs no extremes kernel, and the
     // sort + N50 chain, which needs only lens32, runs beside the tile kernel as well.
     bool pre_ok = false;    // every batch since ppqc_reset went that way
-    bool index_on_main = false;   // ... the newest of them (a one-pass FASTQ text) in line on the main stream, not on the auxiliary one
+    bool index_on_main = false;   // ... the newest of them (a FASTQ text) in line on the main stream, not on the auxiliary one
     bool pre_run = false;   // ... and the finalize in progress relies on it (set by ppqc_finalize_extremes)
     bool n50_early = false; // ppqc_n50_select_early has left the N50 of the run's reads (no batch since)
     hipEvent_t ev_pre = nullptr;   // behind the newest of those kernels (auxiliary stream)
@@ -891,9 +891,14 @@ static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, 
         HIPCHK(launch_tile_kernel(v, c->lut_dev, c->lra, 0, c->head, c->tail, c->dense, c->slow, c->tn, s, true));
     }
     if (hdr_aux) HIPCHK(hipStreamWaitEvent(s, c->ev_hdr, 0));
+    // as in run_fastq_one_pass: sort keys, gate and (a context as ppqc_reset left it) hours and cells with the finalize kernel
+    const bool pre = c->pre_ok && c->res_clean && c->cfg.time_mode == 0 && c->tn.pre != 0;
+    const bool cells = pre && c->cells_early && cmh_packable(c->n_reads + R, c->bases_total + n);
+    Fq1Index ix{pre ? 1 : 0, c->tp, cells ? c->sum_buf + c->tp.lay.off_cmh_bases : nullptr};
     HIPCHK(launch_fastq_finalize(text, n, R, c->fq.line_off, c->lra, c->ra, c->n_reads, c->head, c->tail, shift,
-                                 c->lut_dev, c->qthr, mux, c->res_buf + c->res_words, s, from_sums));
-    return fastq_committed(c, R, n, n_records, false, false, false);
+                                 c->lut_dev, c->qthr, mux, c->res_buf + c->res_words, c->cfg.n_channels,
+                                 c->res_buf + c->res_words + 8, ix, s, from_sums));
+    return fastq_committed(c, R, n, n_records, true, pre, cells);
 }
 
 int ppqc_submit_fastq_device(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, uint64_t* n_records) {

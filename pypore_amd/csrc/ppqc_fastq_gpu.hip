@@ -635,7 +635,8 @@ __device__ __forceinline__ uint32_t fastq_finalize_record(const uint8_t* __restr
                                                           const Partial* __restrict__ head,
                                                           const Partial* __restrict__ tail, uint32_t tile_shift,
                                                           const uint64_t* __restrict__ lut, const QThr& thr,
-                                                          uint64_t* __restrict__ errors) {
+                                                          uint64_t* __restrict__ errors, uint8_t mux, uint32_t n_channels,
+                                                          const Fq1Index& ix, uint32_t* key_out) {
     const uint64_t g = read_base + r;
     uint64_t a[4], e[4];
     uint64_t strip_qb = 0, strip_err = 0;   // what the stripped end of the quality line added to its raw sums
@@ -717,10 +718,20 @@ __device__ __forceinline__ uint32_t fastq_finalize_record(const uint8_t* __restr
     ra.err_hi[g] = hi; ra.err_lo[g] = lw;
     ra.mean_q[g] = mq;
     ra.flags[g] = flags;
+    uint32_t ch = 0;
+    int64_t t = INT64_MIN;
     if (!ok) {   // fastq_header_kernel has parsed the header of what is no record
         ra.channel[g] = 0;
         ra.time[g] = INT64_MIN;
+    } else {
+        ch = ra.channel[g]; t = ra.time[g];
     }
+    // the sort key and (ix.on) hour bin and cell of the read, as fq1_finalize_kernel leaves them: the sort + N50 chain may
+    // start behind this kernel and the finalize of the run needs no extremes kernel over these reads' hours
+    const uint32_t key = (ch >= 1 && ch <= n_channels) ? (uint32_t)Lr : 0u;
+    ra.lens32[g] = key;
+    *key_out = key;
+    if (ix.on) ra.hour[g] = index_cell(ch, (uint32_t)Lr, t, mux, ix.tp, ix.cells);
     return placed;
 }
 
@@ -731,17 +742,24 @@ __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __re
                                                              const Partial* __restrict__ head,
                                                              const Partial* __restrict__ tail, uint32_t tile_shift,
                                                              const uint64_t* __restrict__ lut, QThr thr,
-                                                             uint8_t mux, uint64_t* __restrict__ errors) {
-    __shared__ unsigned int placed_acc;
-    if (threadIdx.x == 0) placed_acc = 0;
+                                                             uint8_t mux, uint64_t* __restrict__ errors,
+                                                             uint32_t n_channels, uint64_t* __restrict__ gate, Fq1Index ix) {
+    __shared__ unsigned int placed_acc, s_max;
+    if (threadIdx.x == 0) { placed_acc = 0; s_max = 0; }
     __syncthreads();
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t placed = 0;
-    if (r < n_records) placed = fastq_finalize_record<WHOLE>(text, r, lo, lra, ra, read_base, head, tail, tile_shift, lut, thr, errors);
+    uint32_t placed = 0, key = 0;
+    if (r < n_records)
+        placed = fastq_finalize_record<WHOLE>(text, r, lo, lra, ra, read_base, head, tail, tile_shift, lut, thr, errors, mux,
+                                              n_channels, ix, &key);
+    if (key) atomicMax(&s_max, key);
     placed = wave_sum_u32(placed);
     if ((threadIdx.x & 63) == 0 && placed) atomicAdd(&placed_acc, placed);
     __syncthreads();   // one atomic per block: the balance is one word
-    if (threadIdx.x == 0 && placed_acc) atomicAdd((unsigned long long*)&errors[6], 0ull - (unsigned long long)placed_acc);
+    if (threadIdx.x == 0) {
+        if (placed_acc) atomicAdd((unsigned long long*)&errors[6], 0ull - (unsigned long long)placed_acc);
+        if (s_max) atomicOr((unsigned long long*)&gate[blockIdx.x & (kGateWords - 1)], (unsigned long long)s_max);   // the sort gate
+    }
 }
 
 hipError_t launch_fastq_header(const uint8_t* text, uint64_t n_records, const uint64_t* line_off, ReadArrays ra,
@@ -755,16 +773,17 @@ hipError_t launch_fastq_header(const uint8_t* text, uint64_t n_records, const ui
 hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
                                  ReadArrays line_ra, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint32_t tile_shift, const uint64_t* lut, const QThr& thr,
-                                 uint8_t mux, uint64_t* errors, hipStream_t s, bool whole_lines) {
+                                 uint8_t mux, uint64_t* errors, uint32_t n_channels, uint64_t* gate, const Fq1Index& ix,
+                                 hipStream_t s, bool whole_lines) {
     if (n_records == 0) return hipSuccess;
     if (whole_lines)
         hipLaunchKernelGGL(fastq_finalize_kernel<true>, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n,
                            n_records, line_off, line_ra, ra, read_base, head, tail, tile_shift, lut, thr, mux,
-                           errors);
+                           errors, n_channels, gate, ix);
     else
         hipLaunchKernelGGL(fastq_finalize_kernel<false>, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n,
                            n_records, line_off, line_ra, ra, read_base, head, tail, tile_shift, lut, thr, mux,
-                           errors);
+                           errors, n_channels, gate, ix);
     return hipGetLastError();
 }
 

@@ -207,6 +207,15 @@ hipError_t launch_line_sums(const uint8_t* text, uint64_t n, uint64_t n_records,
                             const uint64_t* span_sum, const uint64_t* lut_dev, ReadArrays line_ra, hipStream_t s);
 hipError_t launch_nl_place(const uint8_t* text, uint64_t n, uint64_t n_lines, uint64_t n_over, const FastqScratch& fs,
                            uint64_t* errors, hipStream_t s);
+// Part of the index-only results of the text's reads from the finalize kernels of the FASTQ paths (on != 0): their hour bins and, with cells,
+// their packed (channel, mux, hour) cells -- the million-odd atomics that are best issued from a kernel busy with
+// something else.  The extremes follow in extremes_kernel<true> over the run's arrays (launch_batch_extremes, offsets
+// == nullptr), which then leaves hours and cells alone.
+struct Fq1Index {
+    int on;
+    TableParams tp;
+    uint64_t* cells;   // nullptr: no (channel, mux, hour) cells
+};
 // one thread per record: validates the four lines, strips line ends, merges the line sums into the per-read arrays,
 // parses ch= and start_time= out of the header.  errors[1] counts malformed records.
 // channel, mux and start time of every record from its header line (needs the line table only)
@@ -215,7 +224,8 @@ hipError_t launch_fastq_header(const uint8_t* text, uint64_t n_records, const ui
 hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const uint64_t* line_off,
                                  ReadArrays line_ra, ReadArrays ra, uint64_t read_base, const Partial* head,
                                  const Partial* tail, uint32_t tile_shift, const uint64_t* lut, const QThr& thr,
-                                 uint8_t mux, uint64_t* errors, hipStream_t s, bool whole_lines = false);
+                                 uint8_t mux, uint64_t* errors, uint32_t n_channels, uint64_t* gate, const Fq1Index& ix,
+                                 hipStream_t s, bool whole_lines = false);   // also lens32, the sort gate and (ix) hours and cells
 
 // ---- FASTQ text of short lines in one pass (ppqc_fastq1.hip) ---------------------------------------------------------
 constexpr uint32_t kFq1LinesPerChunk = 64;       // share of the point table per 8 KiB chunk of a region (lines)
@@ -230,15 +240,6 @@ uint64_t fq1_chunks(uint64_t n);
 void fq1_shape(uint64_t n, int want_regions, uint32_t* cpr, uint64_t* n_regions);
 hipError_t launch_fq1_scan(const uint8_t* text, uint64_t n, const Fq1Scratch& f, uint32_t cpr, uint64_t n_regions,
                            const uint64_t* lut_dev, uint64_t* host_out, hipStream_t s);
-// Part of the index-only results of the text's reads from the same kernel (on != 0): their hour bins and, with cells,
-// their packed (channel, mux, hour) cells -- the million-odd atomics that are best issued from a kernel busy with
-// something else.  The extremes follow in extremes_kernel<true> over the run's arrays (launch_batch_extremes, offsets
-// == nullptr), which then leaves hours and cells alone.
-struct Fq1Index {
-    int on;
-    TableParams tp;
-    uint64_t* cells;   // nullptr: no (channel, mux, hour) cells
-};
 hipError_t launch_fq1_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const Fq1Scratch& f, uint32_t cpr,
                                uint64_t n_regions, ReadArrays ra, uint64_t read_base, const uint64_t* lut_dev,
                                const QThr& thr, uint8_t mux, uint64_t* errors, uint32_t n_channels, uint64_t* gate,
