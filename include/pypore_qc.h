@@ -362,8 +362,9 @@ int ppqc_bind_thread(ppqc_ctx* ctx);
  * same result (which of the two per-read kernels takes a tile, the tile size, index kernels at submit or at finalize
  * time, how the GPU FASTQ tokenizer sums its lines), `value` -1 leaves the choice to the library -- the state of every
  * new context -- and other values force one path for this context: "tile_dense" 0|1, "dense_len" bytes, "tile_all" 0|1,
- * "tile_shift" 12..16, "pre" 0|1, "fastq_sums" 0|1|2, "fastq_hdr_aux" 0|1|2, "fastq_one_pass" 0|1, "fq1_regions" n
- * (pypore_amd/csrc/ppqc_internal.hpp, Tuning).  Results never depend on it (the parity tests run the paths against each
+ * "tile_shift" 12..16, "pre" 0|1, "fastq_sums" 0|1|2, "fastq_hdr_aux" 0|1|2, "fastq_one_pass" 0|1, "fq1_regions" n,
+ * "sort_beside" 0|1, "n50_select" 0|1 (the local N50 by sort / by radix select), "fastq_index_aux" 0|1 (the extremes of a
+ * FASTQ text's reads in line / beside the tables) (pypore_amd/csrc/ppqc_internal.hpp, Tuning).  Results never depend on it (the parity tests run the paths against each
  * other); the library reads no environment variable. */
 int ppqc_set_tuning(ppqc_ctx* ctx, const char* name, int value);
 /* No counterpart in the reference.  Counters of the same code paths, for the tests that must know which one ran:

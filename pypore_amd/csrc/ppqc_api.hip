@@ -209,6 +209,9 @@ struct ppqc_ctx {
     // sort + N50 chain, which needs only lens32, runs beside the tile kernel as well.
     bool pre_ok = false;    // every batch since ppqc_reset went that way
     bool index_on_main = false;   // ... the newest of them (a FASTQ text) in line on the main stream, not on the auxiliary one
+    bool gate_max_run = true;     // every read of the run so far came from a FASTQ text: the largest gate word is the largest length
+    bool index_pending = false;   // the extremes kernel of the newest text runs on the auxiliary stream and the main stream has not
+                                  // taken its end (ev_pre) in yet: join_index
     bool pre_run = false;   // ... and the finalize in progress relies on it (set by ppqc_finalize_extremes)
     bool n50_early = false; // ppqc_n50_select_early has left the N50 of the run's reads (no batch since)
     hipEvent_t ev_pre = nullptr;   // behind the newest of those kernels (auxiliary stream)
@@ -333,6 +336,16 @@ static int input_errors(const uint64_t* e) {
 
 static int mark_busy(ppqc_ctx* c) {
     c->res_busy = true;
+    return PPQC_OK;
+}
+
+// The extremes of a FASTQ text's reads may still be running on the auxiliary stream (fastq_committed): whatever needs
+// them, or is about to touch the arrays they read, on the main stream takes them in here.
+static int join_index(ppqc_ctx* c) {
+    if (c->index_pending) {
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_pre, 0));
+        c->index_pending = false;
+    }
     return PPQC_OK;
 }
 
@@ -558,6 +571,7 @@ int ppqc_destroy(ppqc_ctx* c) {
 int ppqc_reset(ppqc_ctx* c) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
+    CHK(join_index(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     // one launch clears the results and the words behind them (input errors, length bound, sort gate); the finalize that
     // follows finds the buffer clean and enqueues no clear of its own
@@ -570,6 +584,7 @@ int ppqc_reset(ppqc_ctx* c) {
     c->lens_early = true;
     c->pre_ok = true;
     c->index_on_main = false;
+    c->gate_max_run = true;
     c->pre_run = false;
     c->n50_early = false;
     c->bases_total = 0;
@@ -593,6 +608,7 @@ static int resolve_batch_timings(ppqc_ctx* c, hipEvent_t first_of_last_batch, bo
 // Enqueue the per-read kernels for a batch whose arrays are all in device memory.
 static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     const uint64_t R = b->n_reads;
+    CHK(join_index(c));   // the arrays may grow
     CHK(ensure_reads(c, c->n_reads + R));
     // 64 KiB tiles (a tile's start-up -- the read search, the first loads -- is 3 % of its time; 12 % at 16 KiB), except
     // for batches too small to give every wave slot of the GPU a few tiles: there the kernel's time is the time of its
@@ -629,6 +645,7 @@ static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     HIPCHK(launch_finalize_reads(v, c->ra, base, c->head, c->tail, c->qthr,
                                  c->res_buf + c->res_words, c->cfg.n_channels, c->res_buf + c->res_words + 8, !pre, s));
     if (pre) c->index_on_main = false;
+    c->gate_max_run = false;   // finalize_reads and the index kernel raise the gate by OR
     if (pre) {
         // Enqueued behind the batch's kernels in host order (every call in front of the tile kernel's launch delays its
         // start) and ordered on the device behind the batch's start event, i.e. behind whatever produced the index on
@@ -744,13 +761,18 @@ static int fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_reco
         HIPCHK(hipEventRecord(c->ev_reads, c->stream));
         ++c->reads_gen;
         if (pre) {
-            // hours and cells are there (fq1_finalize_kernel); the extremes over the run's arrays, in line on the main
-            // stream (nothing to run beside)
+            // hours and cells are there (the text's finalize kernel); the extremes over the run's arrays.  When the run
+            // holds reads of texts only, on the auxiliary stream: the gate's largest word is the largest length then, the
+            // one thing the tables kernel needs of the extremes, so that kernel runs beside this one (ppqc_finalize) and
+            // the N50 chain behind it.  Else in line on the main stream.
+            const bool on_aux = c->gate_max_run && c->tn.fastq_index_aux != 0;
+            hipStream_t es = on_aux ? c->aux : c->stream;
+            if (on_aux) HIPCHK(hipStreamWaitEvent(es, c->ev_reads, 0));
             BatchView v{nullptr, nullptr, nullptr, R, n, nullptr, kDefaultTileShift, nullptr, nullptr, nullptr};
             HIPCHK(launch_batch_extremes(v, c->n_reads, c->ra, c->tp, c->max_buf, c->min_buf, c->tminmax,
-                                         c->res_buf + c->res_words + 4, c->maxlen_host + 4, nullptr,
-                                         c->res_buf + c->res_words + 8, c->stream));
-            HIPCHK(hipEventRecord(c->ev_pre, c->stream));
+                                         c->res_buf + c->res_words + 4, c->maxlen_host + 4, nullptr, nullptr, es));
+            HIPCHK(hipEventRecord(c->ev_pre, es));
+            c->index_pending = on_aux;
             c->index_on_main = true;   // whoever takes these results on the auxiliary stream waits for ev_pre (finalize_impl)
             if (cells) c->cells_dirty = true;
             c->last_b = nullptr;   // no per-read kernel whose end the sort chain could start at: behind ev_reads
@@ -759,6 +781,7 @@ static int fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_reco
     } else if (R) {
         c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
     }
+    if (R && !(lens_written && pre)) c->gate_max_run = false;
     if (R && !cells) c->cells_early = false;
     c->n_reads += R;
     c->state = 0;
@@ -820,6 +843,7 @@ static int run_fastq_one_pass(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint
 static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, uint64_t* n_records) {
     if (n_records) *n_records = 0;
     if (n == 0) return PPQC_OK;
+    CHK(join_index(c));   // the arrays may grow
     hipStream_t s = c->stream;
     const int op = c->tn.fastq_one_pass;
     if (op == 1 || (op < 0 && c->fq_line_hint >= kFq1MinLine && c->fq_line_hint < kFq1MaxLine)) {
@@ -940,6 +964,7 @@ int ppqc_submit_records(ppqc_ctx* c, const ppqc_records* r) {
     if (!r->length || !r->mean_q || !r->channel || !r->mux || !r->start_time_s)
         return fail(PPQC_E_INVALID, "null record column");
     HIPCHK(hipSetDevice(c->device));
+    CHK(join_index(c));   // the arrays may grow
     CHK(ensure_reads(c, c->n_reads + n));
     // stage the columns in one device buffer (freed after the kernel; this path is I/O bound on the text table)
     const uint64_t o_len = 0, o_q = o_len + n * 4 + 8, o_q8 = (o_q + 7) & ~7ull, o_gc = o_q8 + n * 8,
@@ -962,6 +987,7 @@ int ppqc_submit_records(ppqc_ctx* c, const ppqc_records* r) {
     c->state = 0;
     c->lens_early = false;   // lens32 of these reads is written by the extremes kernel
     c->pre_ok = false;
+    c->gate_max_run = false;
     c->cells_early = c->cells_done = c->cmh_on_host = false;
     for (uint64_t i = 0; i < n; ++i) c->bases_total += r->length[i];
     return PPQC_OK;
@@ -1019,6 +1045,7 @@ static int resolve_timings(ppqc_ctx* c) {   // everything, behind a synchronisat
 int ppqc_sync(ppqc_ctx* c) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
+    CHK(join_index(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 2; ++i) c->slot[i].busy = false;
     c->res_busy = false;
@@ -1078,10 +1105,12 @@ int ppqc_read_hours(ppqc_ctx* c, int32_t* out, uint64_t first, uint64_t n) {
     return PPQC_OK;
 }
 
-int ppqc_finalize_extremes(ppqc_ctx* c) {
+// defer_index: the caller (ppqc_finalize) takes the end of a FASTQ text's extremes kernel in itself, behind the tables
+static int finalize_extremes_impl(ppqc_ctx* c, bool defer_index) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    if (!(defer_index && c->res_clean && c->pre_ok && c->gate_max_run)) CHK(join_index(c));
     resolve_finalize_timings(c);   // its events are about to be recorded again
     c->fin_gen = c->reads_gen;
     c->sum_fetched = false;
@@ -1126,6 +1155,8 @@ int ppqc_finalize_extremes(ppqc_ctx* c) {
     c->state = 1;
     return mark_busy(c);
 }
+
+int ppqc_finalize_extremes(ppqc_ctx* c) { return finalize_extremes_impl(c, false); }
 
 int ppqc_time_range(ppqc_ctx* c, int64_t* out2) {
     if (!c || !out2) return fail(PPQC_E_INVALID, "null argument");
@@ -1194,7 +1225,12 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
         c->cells_done = true;
         c->cmh_on_host = false;
     }
-    HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, c->max_buf, c->tab_slab, s, cell_mode, c->cc_ready ? c->cc : nullptr));
+    // the largest length: left by an extremes kernel in front of this one, or (that kernel still runs beside, on the
+    // auxiliary stream) the largest word of the gate, which the finalize kernels of the run's FASTQ texts have raised
+    const bool from_gate = c->index_pending && c->pre_run && c->gate_max_run;
+    if (!from_gate) CHK(join_index(c));
+    HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, from_gate ? c->res_buf + c->res_words + 8 : c->max_buf,
+                         from_gate ? kGateWords : 1, c->tab_slab, s, cell_mode, c->cc_ready ? c->cc : nullptr));
     c->state = 2;
     if (c->n50_early) {   // the N50 is there already (ppqc_n50_select_early): the finalize ends here
         HIPCHK(hipEventRecord(c->ev_t1, s));
@@ -1241,6 +1277,8 @@ static int cells_to_host_on(ppqc_ctx* c, hipStream_t st, hipStream_t cs) {
     return PPQC_OK;
 }
 
+static const int kSelShift[3] = {21, 10, 0}, kSelBits[3] = {11, 11, 10};
+
 static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, bool early_fetch) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     if (c->state < 1) return fail(PPQC_E_STATE, "call ppqc_finalize_extremes first");
@@ -1268,6 +1306,12 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     // (not behind a one-pass FASTQ text: its extremes end just in front of this call, the host would wait for them with
     // nothing enqueued behind; the chain starts behind the text's last per-read kernel, gated on the device)
     const bool pre = local && c->pre_run && ss != s && !c->index_on_main;
+    // By radix select instead (three histograms of the lengths and three one-block picks: six short launches that read the
+    // lengths three times, where the sort reads and writes them once per byte of the largest): behind a FASTQ text, whose
+    // lengths are the last thing known, so that the chain is the tail of the step (4.3 * 10^6 reads: 205 -> 45 us).  The
+    // histogram and its state are as ppqc_reset left them (pre_run), and each pick clears the histogram for the next.
+    const bool by_select = local && c->pre_run && ss != s && (c->tn.n50_select >= 0 ? c->tn.n50_select != 0 : c->index_on_main);
+    if (ss == s) CHK(join_index(c));
     // pre: the keys come from the batches' index kernels, so the chain does not wait for finalize_reads either: it starts
     // when the per-read kernel ends and runs beside finalize_reads and the tables
     // ... and beside the per-read kernel itself, right behind the index kernels, when that kernel is dense_kernel alone:
@@ -1282,7 +1326,13 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     // which carries the device's not yet final n50_out along, cannot overwrite it.
     const bool early_out = early_fetch && c->state == 2 && ss != s;
     uint64_t* host_out = early_out ? c->res_host + c->res_words + 7 : nullptr;
-    if (pre) {
+    if (by_select) {
+        for (int r = 0; r < 3; ++r) {
+            HIPCHK(launch_select_hist(dlens, n, kSelShift[r], kSelBits[r], c->sel_state, c->sel_buf, ss));
+            HIPCHK(launch_select_pick(c->sel_buf, nullptr, c->sel_state, kSelShift[r], kSelBits[r], r == 2, r == 0,
+                                      c->n50_out, host_out, ss));
+        }
+    } else if (pre) {
         HIPCHK(hipEventSynchronize(c->ev_pre));   // a wait of the host while the GPU is busy with the tile kernel
         const uint64_t m = c->maxlen_host[4];
         const uint32_t mask = m < (1ull << 8) ? 1u : (m < (1ull << 16) ? 3u : (m < (1ull << 24) ? 7u : 15u));
@@ -1297,6 +1347,7 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     if (ss == s) HIPCHK(hipEventRecord(c->ev_s1, ss));
     if (ss != s) {
         if (early_out) {   // ppqc_finalize: all but the N50 is final behind the tables kernel; copied beside the sort chain
+            CHK(join_index(c));   // (and behind the extremes of a FASTQ text, which ran beside the tables)
             CHK(copy_results(c, s));
             c->sum_fetched = true;
         }
@@ -1304,6 +1355,7 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
         c->sort_end = c->ev_join;
         HIPCHK(hipEventRecord(c->ev_t1, s));      // end of the main chain; the finalize ends at the later of the two
         HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+        c->index_pending = false;   // ev_join lies behind that kernel on the auxiliary stream
     } else {
         HIPCHK(hipEventRecord(c->ev_t1, s));
     }
@@ -1364,7 +1416,7 @@ int ppqc_fetch_tables(ppqc_ctx* c, ppqc_tables* o) { return fetch_tables_impl(c,
 int ppqc_fetch_tables_view(ppqc_ctx* c, ppqc_tables* o) { return fetch_tables_impl(c, o, true); }
 
 static int finalize_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
-    CHK(ppqc_finalize_extremes(c));
+    CHK(finalize_extremes_impl(c, true));
     // Every batch left its cells with its index kernel: unpack them on the auxiliary stream, right behind those kernels,
     // and copy the region (13.8 MB at 3000 x 4 x 72, the bulk of the result buffer) to the host mirror on a copy stream --
     // all of it beside the per-read kernel, which this call usually finds running.
@@ -1397,8 +1449,6 @@ int ppqc_device_tables_view(ppqc_ctx* c, ppqc_device_tables* o) {
     return PPQC_OK;
 }
 
-static const int kSelShift[3] = {21, 10, 0}, kSelBits[3] = {11, 11, 10};
-
 int ppqc_n50_select_hist(ppqc_ctx* c, int round) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     if (round < 0 || round > 2) return fail(PPQC_E_INVALID, "round must be 0, 1 or 2");
@@ -1424,7 +1474,7 @@ int ppqc_n50_select_pick(ppqc_ctx* c, int round) {
     if (c->state < 2) return fail(PPQC_E_STATE, "call ppqc_finalize_tables first (the pick needs the merged total)");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(launch_select_pick(c->sel_buf, c->sum_buf + c->tp.lay.off_totals + PPQC_TOT_N_BASES, c->sel_state,
-                              kSelShift[round], kSelBits[round], round == 2, false, c->n50_out, c->stream));
+                              kSelShift[round], kSelBits[round], round == 2, false, c->n50_out, nullptr, c->stream));
     if (round == 2) {
         HIPCHK(hipEventRecord(c->ev_s1, c->stream));
         c->sort_end = c->ev_s1;
@@ -1463,7 +1513,7 @@ int ppqc_n50_select_early(ppqc_ctx* c, int round, int phase, void* stream) {
         HIPCHK(launch_select_hist(c->ra.lens32, c->n_reads, kSelShift[round], kSelBits[round], c->sel_state, c->sel_buf, ss));
     } else {
         HIPCHK(launch_select_pick(c->sel_buf, nullptr, c->sel_state, kSelShift[round], kSelBits[round], round == 2,
-                                  round == 0, c->n50_out, ss));
+                                  round == 0, c->n50_out, nullptr, ss));
         if (round == 2) c->n50_early = true;
     }
     return mark_busy(c);
@@ -1553,6 +1603,7 @@ int ppqc_set_tuning(ppqc_ctx* c, const char* name, int value) {
         {"tile_all", &c->tn.tile_all, -1, 1},           {"tile_shift", &c->tn.tile_shift, -1, kMaxTileShift},
         {"pre", &c->tn.pre, -1, 1},                     {"fastq_sums", &c->tn.fastq_sums, -1, 2},
         {"fastq_hdr_aux", &c->tn.fastq_hdr_aux, -1, 2}, {"sort_beside", &c->tn.sort_beside, -1, 1},
+        {"n50_select", &c->tn.n50_select, -1, 1}, {"fastq_index_aux", &c->tn.fastq_index_aux, -1, 1},
         {"fastq_one_pass", &c->tn.fastq_one_pass, -1, 1}, {"fq1_regions", &c->tn.fq1_regions, -1, 1 << 20},
     };
     for (auto& k : knobs)

@@ -671,7 +671,9 @@ __global__ __launch_bounds__(256) void fq1_finalize_kernel(const uint8_t* __rest
     if (threadIdx.x == 0) {
         if (s_mis) atomicAdd((unsigned long long*)&errors[6], (unsigned long long)s_mis);
         if (s_bad) atomicAdd((unsigned long long*)&errors[3], (unsigned long long)s_bad);
-        if (s_max) atomicOr((unsigned long long*)&gate[blockIdx.x & (kGateWords - 1)], (unsigned long long)s_max);
+        // by atomicMax: the words still bound every key by their OR, and their largest is the largest length of the texts
+        // (tables_kernel takes it from here when no extremes kernel has run in front of it)
+        if (s_max) atomicMax((unsigned long long*)&gate[blockIdx.x & (kGateWords - 1)], (unsigned long long)s_max);
     }
 }
 

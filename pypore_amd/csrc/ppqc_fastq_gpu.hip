@@ -758,7 +758,8 @@ __global__ __launch_bounds__(256) void fastq_finalize_kernel(const uint8_t* __re
     __syncthreads();   // one atomic per block: the balance is one word
     if (threadIdx.x == 0) {
         if (placed_acc) atomicAdd((unsigned long long*)&errors[6], 0ull - (unsigned long long)placed_acc);
-        if (s_max) atomicOr((unsigned long long*)&gate[blockIdx.x & (kGateWords - 1)], (unsigned long long)s_max);   // the sort gate
+        // the sort gate, by atomicMax as in fq1_finalize_kernel: the largest word is the largest length of the texts
+        if (s_max) atomicMax((unsigned long long*)&gate[blockIdx.x & (kGateWords - 1)], (unsigned long long)s_max);
     }
 }
 

@@ -107,6 +107,10 @@ struct Tuning {
     int fastq_hdr_aux = -1; // FASTQ text: 0 header kernel in front of the line pass, 2 beside it, -1 / 1 beside line_sum only
     int fastq_one_pass = -1;  // FASTQ text: 1 the one-pass kernels of ppqc_fastq1.hip for every text, 0 never, -1 by the last text's lines
     int fq1_regions = -1;     // ... the number of regions (waves) they split a text into (4096)
+    int n50_select = -1;      // local N50: 1 by radix select (three histograms of the lengths) whenever the run left its index at
+                              // submit time, 0 by the sort; -1: select behind FASTQ texts, whose lengths are known last
+    int fastq_index_aux = -1; // FASTQ text: 0 the extremes kernel in line behind the finalize kernel; -1 / 1 on the auxiliary stream
+                              // when every read of the run came from a text (the tables take the largest length from the gate)
 };
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
                               Partial* head, Partial* tail, DenseList& dl, DenseList& slow, const Tuning& tn, hipStream_t s,
@@ -136,8 +140,10 @@ hipError_t launch_cells(ReadArrays ra, uint64_t n, const TableParams& tp, uint64
 // per read + cmh_unpack, 2: two atomics per read
 // slab: tables_slab_words(layout) u64 of scratch (every block leaves its private tables there; a second kernel adds them up)
 uint64_t tables_slab_words(const TableLayout& lay);
+// max_buf[0 .. max_words): words whose largest is the run's largest length (max_buf of the extremes kernels, 1 word; or the
+// sort gate, kGateWords words, when the FASTQ finalize kernels alone have raised it)
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
-                         uint64_t* slab, hipStream_t s, int cell_mode, const uint64_t* job_chan_count = nullptr);
+                         int max_words, uint64_t* slab, hipStream_t s, int cell_mode, const uint64_t* job_chan_count = nullptr);
 hipError_t launch_chan_count(ReadArrays ra, uint64_t n, uint32_t n_channels, uint64_t* out, hipStream_t s);
 
 hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s);
@@ -184,7 +190,8 @@ hipError_t launch_n50_gated(const uint32_t* in, const uint32_t* buf_a, const uin
 hipError_t launch_select_hist(const uint32_t* lens, uint64_t n, int shift, int nbits, const uint64_t* state,
                               uint64_t* sel, hipStream_t s);
 hipError_t launch_select_pick(uint64_t* sel, const uint64_t* total, uint64_t* state, int shift, int nbits, bool last,
-                              bool first, uint64_t* out, hipStream_t s);   // total == nullptr: from the first round's histogram
+                              bool first, uint64_t* out, uint64_t* host_out, hipStream_t s);   // total == nullptr: from the first
+                              // round's histogram; host_out (last round, may be null): a pinned word that receives the N50 as well
 
 // ---- FASTQ text on the GPU (ppqc_fastq_gpu.hip) --------------------------------------------------------------------
 constexpr uint32_t kNlChunk = 8192;   // bytes of text per wave of the line-index kernels (eight 1 KiB spans in registers)

@@ -395,7 +395,8 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const uint32_t* __rest
 // whole select independent of the tables, so it can run as soon as the lengths are known.
 __global__ __launch_bounds__(256) void select_pick_kernel(uint64_t* __restrict__ sel, const uint64_t* __restrict__ total,
                                                           uint64_t* __restrict__ state, int shift, int nbits, int last,
-                                                          int first, uint64_t* __restrict__ out) {
+                                                          int first, uint64_t* __restrict__ out,
+                                                          uint64_t* __restrict__ host_out) {
     __shared__ uint64_t part[256];
     __shared__ uint64_t s_T;
     const uint32_t t = threadIdx.x;
@@ -423,14 +424,20 @@ __global__ __launch_bounds__(256) void select_pick_kernel(uint64_t* __restrict__
             const uint64_t np = prefix | ((uint64_t)(t * per + k) << shift);
             state[0] = np;
             state[1] = after;
-            if (last) out[0] = np;
+            if (last) {
+                out[0] = np;
+                if (host_out) host_out[0] = np;
+            }
         }
         after = suf;
     }
     for (int d = t; d < PPQC_N_SEL; d += 256) sel[d] = 0;
     if (last && t == 0) {
         out[1] = T;
-        if (T == 0) out[0] = 0;
+        if (T == 0) {
+            out[0] = 0;
+            if (host_out) host_out[0] = 0;
+        }
     }
 }
 
@@ -444,9 +451,9 @@ hipError_t launch_select_hist(const uint32_t* lens, uint64_t n, int shift, int n
 }
 
 hipError_t launch_select_pick(uint64_t* sel, const uint64_t* total, uint64_t* state, int shift, int nbits, bool last,
-                              bool first, uint64_t* out, hipStream_t s) {
+                              bool first, uint64_t* out, uint64_t* host_out, hipStream_t s) {
     hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, s, sel, total, state, shift, nbits, last ? 1 : 0,
-                       first ? 1 : 0, out);
+                       first ? 1 : 0, out, last ? host_out : nullptr);
     return hipGetLastError();
 }
 

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(1024) void extremes_kernel(BatchView b, uint64_t ba
         atomicMax((long long*)&tminmax[1], s_tmax);
         if (BATCH) {
             // the sort gate (words whose OR bounds every sort key of the run: finalize_reads_kernel raises it otherwise)
-            if (s_max) atomicOr((unsigned long long*)&gate[blockIdx.x & (kGateWords - 1)], s_max);
+            // (not for the reads of a FASTQ text: their finalize kernel has raised it, and keeps the largest length in it)
+            if (gate && s_max) atomicOr((unsigned long long*)&gate[blockIdx.x & (kGateWords - 1)], s_max);
             __threadfence();
             const unsigned long long ticket = atomicAdd((unsigned long long*)&bound[1], 1ull);
             if (ticket == gridDim.x - 1ull) {
@@ -214,8 +215,8 @@ constexpr uint32_t kHistBins = PPQC_N_LEN_LOG2 + PPQC_N_LEN_LIN + PPQC_N_QHIST +
 constexpr unsigned kTabThreads = 512, kTabMaxBlocks = 512;
 
 __global__ __launch_bounds__(kTabThreads) void tables_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf,
-                                                            const uint64_t* max_buf, uint32_t nchL, int cell_mode,
-                                                            uint64_t* __restrict__ slab) {
+                                                            const uint64_t* max_buf, int max_words, uint32_t nchL,
+                                                            int cell_mode, uint64_t* __restrict__ slab) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t nb = tp.lay.n_time_bins, nch = tp.lay.n_channels, nmux = tp.lay.n_mux;
     unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(smem);
@@ -235,7 +236,11 @@ __global__ __launch_bounds__(kTabThreads) void tables_kernel(ReadArrays ra, uint
     __syncthreads();
 
     unsigned long long* g = reinterpret_cast<unsigned long long*>(sum_buf);
-    const uint64_t lin_w = max_buf[0] / PPQC_N_LEN_LIN + 1;
+    // the run's largest length: max_buf[0] behind an extremes kernel, or the largest of the sort gate's words when every
+    // read of the run came from a FASTQ text (their finalize kernels raise each word by atomicMax)
+    uint64_t run_max = 0;
+    for (int k = 0; k < max_words; ++k) run_max = max_buf[k] > run_max ? max_buf[k] : run_max;
+    const uint64_t lin_w = run_max / PPQC_N_LEN_LIN + 1;
     const bool chan_lds = nchL != 0;
     const uint32_t rep = threadIdx.x & (kRep - 1);
 
@@ -533,7 +538,7 @@ hipError_t launch_cmh_unpack(const TableParams& tp, uint64_t* sum_buf, hipStream
 uint64_t tables_slab_words(const TableLayout& lay) { return (uint64_t)kTabMaxBlocks * lay.off_cmh_reads; }
 
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
-                         uint64_t* slab, hipStream_t s, int cell_mode, const uint64_t* job_chan_count) {
+                         int max_words, uint64_t* slab, hipStream_t s, int cell_mode, const uint64_t* job_chan_count) {
     if (n == 0) return hipSuccess;
     const uint32_t nb = tp.lay.n_time_bins;
     // per-channel accumulators in LDS need 16 B per channel; a block stays under 64 KiB, so two fit a CU.  When
@@ -546,8 +551,8 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     // two blocks of 512 threads per CU (4 waves per SIMD): the kernel is bound by the latency of its eleven loads per read
     const unsigned blocks = grid_for(n, kTabMaxBlocks);
-    hipLaunchKernelGGL(tables_kernel, dim3(blocks), dim3(kTabThreads), lds, s, ra, n, tp, sum_buf, max_buf, nchL, cell_mode,
-                       slab);
+    hipLaunchKernelGGL(tables_kernel, dim3(blocks), dim3(kTabThreads), lds, s, ra, n, tp, sum_buf, max_buf, max_words, nchL,
+                       cell_mode, slab);
     hipLaunchKernelGGL(tables_reduce_kernel, dim3((unsigned)((tp.lay.off_cmh_reads + 15) / 16)), dim3(256), 0, s, slab, blocks,
                        (uint32_t)tp.lay.off_cmh_reads, sum_buf);
     if (cell_mode == 1) {

@@ -516,3 +516,60 @@ def test_a_text_of_short_reads_at_size(qc_mod, c_oracle, line_sums_from):
         if line_sums_from == "auto":
             assert ctx.path_count("fastq_one_pass") == 1
         assert_tables_equal(ctx.finalize(), wt)
+
+
+TAILS = [dict(), dict(fastq_index_aux=0), dict(n50_select=0), dict(fastq_index_aux=0, n50_select=0), dict(n50_select=1)]
+
+
+@pytest.mark.parametrize("tail", TAILS, ids=lambda t: ",".join("%s=%d" % kv for kv in t.items()) or "default")
+def test_the_tail_of_a_step_straight_behind_the_texts(qc_mod, c_oracle, tail):
+    """ppqc_finalize with nothing between it and the texts (no ppqc_sync: the extremes kernel of the last text may still
+    run on the auxiliary stream, the tables take the largest length from the sort gate, the N50 comes from the radix
+    select) against the same with the extremes in line and / or the N50 by sort, in runs of one text, of several texts,
+    of a CSR batch and texts in either order (the gate then holds ORs, the tables wait for the extremes), of texts whose
+    reads have no valid channel (every sort key 0), and a second finalize of the same reads."""
+    from pypore_amd import fastq_io
+    rng = np.random.default_rng(77)
+    lens_a = [int(x) for x in rng.integers(1, 700, 900)] + [40_000, 0, 3]
+    lens_b = [int(x) for x in rng.integers(100, 300, 1500)]
+    lens_c = [70_000, 5, 131_073] + [int(x) for x in rng.integers(1, 5000, 300)]
+    texts = [_text(201, len(lens_a), lens=lens_a), _text(202, len(lens_b), lens=lens_b, crlf=True),
+             _text(203, len(lens_c), lens=lens_c)]
+    packs = [fastq_io.pack_fastq(t) for t in texts]
+
+    def expect(order):
+        stats = [c_oracle.per_read(packs[k]["bases"], packs[k]["quals"], packs[k]["offsets"], nthreads=2) for k in order]
+        want = {k: np.concatenate([s[k] for s in stats]) for k in ("length", "gc", "n", "qsum", "mean_q")}
+        want["err"] = [e for s in stats for e in s["err"]]
+        ch = np.concatenate([packs[k]["channel"] for k in order])
+        st = np.concatenate([packs[k]["start_time"] for k in order])
+        return c_oracle.tables(want, ch, np.ones(len(ch), np.uint8), st, None, CFG)
+
+    def as_batch(ctx, k):
+        p = packs[k]
+        ctx.submit(p["bases"], p["quals"], p["offsets"], p["channel"], np.ones(p["n_reads"], np.uint8), p["start_time"])
+
+    with qc_mod.QCContext(device=0, **CFG) as ctx:
+        for name, value in tail.items():
+            ctx.set_tuning(name, value)
+        for plan in ([("t", 0)], [("t", 1), ("t", 0), ("t", 2)], [("b", 2), ("t", 1)], [("t", 1), ("b", 0)],
+                     [("t", 0), ("b", 1), ("t", 2)]):
+            ctx.reset()
+            for kind, k in plan:
+                if kind == "t":
+                    assert ctx.submit_fastq(texts[k], slot=k % 2) == packs[k]["n_reads"]
+                else:
+                    as_batch(ctx, k)
+            wt = expect([k for _, k in plan])
+            assert_tables_equal(ctx.finalize(), wt, str(plan))
+            assert_tables_equal(ctx.finalize(), wt, "again " + str(plan))   # the same reads once more, without a reset
+        # no read with a valid channel: every key is 0, the gate stays 0, N50 0
+        bare = _text(204, 300, lens=[int(x) for x in rng.integers(1, 400, 300)], fields=False)
+        pb = fastq_io.pack_fastq(bare)
+        sb = c_oracle.per_read(pb["bases"], pb["quals"], pb["offsets"], nthreads=2)
+        wb = c_oracle.tables(sb, pb["channel"], np.ones(300, np.uint8), pb["start_time"], None, CFG)
+        ctx.reset()
+        assert ctx.submit_fastq(bare) == 300
+        got = ctx.finalize()
+        assert_tables_equal(got, wb, "no channels")
+        assert int(got["n50"]) == 0
