@@ -210,7 +210,7 @@ struct ppqc_ctx {
     bool pre_ok = false;    // every batch since ppqc_reset went that way
     bool index_on_main = false;   // ... the newest of them (a FASTQ text) in line on the main stream, not on the auxiliary one
     bool gate_max_run = true;     // every read of the run so far came from a FASTQ text: the largest gate word is the largest length
-    bool index_pending = false;   // the extremes kernel of the newest text runs on the auxiliary stream and the main stream has not
+    bool index_pending = false;   // the extremes kernel of the newest text runs on a stream of its own and the main stream has not
                                   // taken its end (ev_pre) in yet: join_index
     bool pre_run = false;   // ... and the finalize in progress relies on it (set by ppqc_finalize_extremes)
     bool n50_early = false; // ppqc_n50_select_early has left the N50 of the run's reads (no batch since)
@@ -263,8 +263,10 @@ static int grow(T** p, uint64_t old_n, uint64_t new_cap, hipStream_t s) {
     return PPQC_OK;
 }
 
+static int join_index(ppqc_ctx* c);
 static int ensure_reads(ppqc_ctx* c, uint64_t need) {
     if (need <= c->cap_reads) return PPQC_OK;
+    CHK(join_index(c));   // the extremes kernel of a FASTQ text may be reading the arrays that move
     uint64_t cap = c->cap_reads ? c->cap_reads * 2 : 1024;
     if (cap < need) cap = need;
     const uint64_t n = c->n_reads;
@@ -339,7 +341,7 @@ static int mark_busy(ppqc_ctx* c) {
     return PPQC_OK;
 }
 
-// The extremes of a FASTQ text's reads may still be running on the auxiliary stream (fastq_committed): whatever needs
+// The extremes of a FASTQ text's reads may still be running on a stream of their own (fastq_committed): whatever needs
 // them, or is about to touch the arrays they read, on the main stream takes them in here.
 static int join_index(ppqc_ctx* c) {
     if (c->index_pending) {
@@ -608,7 +610,7 @@ static int resolve_batch_timings(ppqc_ctx* c, hipEvent_t first_of_last_batch, bo
 // Enqueue the per-read kernels for a batch whose arrays are all in device memory.
 static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     const uint64_t R = b->n_reads;
-    CHK(join_index(c));   // the arrays may grow
+    CHK(join_index(c));   // a text's extremes kernel and this batch's index kernel share their ticket word
     CHK(ensure_reads(c, c->n_reads + R));
     // 64 KiB tiles (a tile's start-up -- the read search, the first loads -- is 3 % of its time; 12 % at 16 KiB), except
     // for batches too small to give every wave slot of the GPU a few tiles: there the kernel's time is the time of its
@@ -762,11 +764,12 @@ static int fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_reco
         ++c->reads_gen;
         if (pre) {
             // hours and cells are there (the text's finalize kernel); the extremes over the run's arrays.  When the run
-            // holds reads of texts only, on the auxiliary stream: the gate's largest word is the largest length then, the
-            // one thing the tables kernel needs of the extremes, so that kernel runs beside this one (ppqc_finalize) and
-            // the N50 chain behind it.  Else in line on the main stream.
+            // holds reads of texts only, on a stream of its own (the first copy stream: a text's copy into that slot waits
+            // for the kernels of the slot's last text anyway): the gate's largest word is the largest length then, the
+            // one thing the tables kernel needs of the extremes, so that kernel (main stream) and the N50 chain
+            // (auxiliary stream) run beside this one (ppqc_finalize).  Else in line on the main stream.
             const bool on_aux = c->gate_max_run && c->tn.fastq_index_aux != 0;
-            hipStream_t es = on_aux ? c->aux : c->stream;
+            hipStream_t es = on_aux ? c->copy[0] : c->stream;
             if (on_aux) HIPCHK(hipStreamWaitEvent(es, c->ev_reads, 0));
             BatchView v{nullptr, nullptr, nullptr, R, n, nullptr, kDefaultTileShift, nullptr, nullptr, nullptr};
             HIPCHK(launch_batch_extremes(v, c->n_reads, c->ra, c->tp, c->max_buf, c->min_buf, c->tminmax,
@@ -843,7 +846,6 @@ static int run_fastq_one_pass(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint
 static int run_fastq(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint8_t mux, uint64_t* n_records) {
     if (n_records) *n_records = 0;
     if (n == 0) return PPQC_OK;
-    CHK(join_index(c));   // the arrays may grow
     hipStream_t s = c->stream;
     const int op = c->tn.fastq_one_pass;
     if (op == 1 || (op < 0 && c->fq_line_hint >= kFq1MinLine && c->fq_line_hint < kFq1MaxLine)) {
@@ -1355,7 +1357,7 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
         c->sort_end = c->ev_join;
         HIPCHK(hipEventRecord(c->ev_t1, s));      // end of the main chain; the finalize ends at the later of the two
         HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
-        c->index_pending = false;   // ev_join lies behind that kernel on the auxiliary stream
+        CHK(join_index(c));
     } else {
         HIPCHK(hipEventRecord(c->ev_t1, s));
     }

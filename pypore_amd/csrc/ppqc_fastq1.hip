@@ -32,9 +32,10 @@
 
 namespace ppqc {
 
-constexpr int kFq1Vecs = 8;              // 16-byte vectors of a lane's strip
-constexpr int kFq1Cap = 512;             // newline vectors of one chunk the wave's buffer holds: every vector of it
-constexpr int kFq1Keep = 48;             // ... of which the first few keep their 16 bytes in LDS as well (500-base reads: 28 per chunk)
+constexpr int kFq1Vecs = 8;              // 16-byte vectors of half a strip: a lane's 256-byte strip is two runs of eight
+constexpr int kFq1Cap = 512;             // newline vectors of one chunk the wave's buffer holds (of 1024 vectors: a chunk with more
+                                         // has lines of 32 bytes, four times what the point table is made for -> declined)
+constexpr int kFq1Keep = 64;             // ... of which the first few keep their 16 bytes in LDS as well (500-base reads: 56 per chunk)
 constexpr int kF1Gcs = 55, kF1N = 58, kF1Odd = 61;   // three-bit counters above the 55 bits of an error sum of <= 7 bytes
 constexpr uint64_t kF1Err = (1ull << 55) - 1;
 constexpr uint64_t kM48 = (1ull << 48) - 1;
@@ -50,7 +51,11 @@ __device__ __forceinline__ uint64_t lut2_entry(uint32_t b, uint64_t err) {
     return v;
 }
 
-struct F1Sums { uint64_t err; uint32_t gno; };   // gno = G/C/S | N << 8 | odd << 16
+// gno = G/C/S | N << 12 | odd << 24: the three counts of some bytes side by side (the top one has eight bits: 255 bytes)
+struct F1Sums { uint64_t err; uint32_t gno; };
+__device__ __forceinline__ uint32_t gno_g(uint32_t gno) { return gno & 0xFFFu; }
+__device__ __forceinline__ uint32_t gno_n(uint32_t gno) { return (gno >> 12) & 0xFFFu; }
+__device__ __forceinline__ uint32_t gno_o(uint32_t gno) { return gno >> 24; }
 __device__ __forceinline__ F1Sums f1_sums(const uint4& x, const uint64_t* lut2) {
     // three accumulators (6, 5 and 5 bytes): their error sums stay below 2^55 and their counters below 8
     const uint64_t a0 = lut2[x.x & 0xffu] + lut2[(x.x >> 8) & 0xffu] + lut2[(x.x >> 16) & 0xffu] + lut2[x.x >> 24] +
@@ -59,51 +64,67 @@ __device__ __forceinline__ F1Sums f1_sums(const uint4& x, const uint64_t* lut2) 
                         lut2[(x.z >> 16) & 0xffu];
     const uint64_t a2 = lut2[x.z >> 24] + lut2[x.w & 0xffu] + lut2[(x.w >> 8) & 0xffu] + lut2[(x.w >> 16) & 0xffu] +
                         lut2[x.w >> 24];
+    // the nine counter bits of each accumulator; their plain sum times 2^55 is what the three counter fields add to
+    // a0 + a1 + a2 (mod 2^64), so taking it off leaves the error sum (< 2^57) without masking each accumulator first
+    const uint32_t y0 = (uint32_t)(a0 >> 55), y1 = (uint32_t)(a1 >> 55), y2 = (uint32_t)(a2 >> 55);
     F1Sums s;
-    s.err = (a0 & kF1Err) + (a1 & kF1Err) + (a2 & kF1Err);
-    // the three accumulators' counters side by side, nine bits each; a 24-bit multiply by 1 + 2^9 + 2^18 leaves the sum
-    // of a counter's three copies at bit 18 (no carry reaches it: two copies sum to 11 at most below it)
-    const uint32_t y = (uint32_t)(a0 >> 55) | ((uint32_t)(a1 >> 55) << 9) | ((uint32_t)(a2 >> 55) << 18);
-    const uint32_t g = (__umul24(y & 0x1C0E07u, 0x40201u) >> 18) & 31u;
-    const uint32_t nn = (__umul24((y >> 3) & 0x1C0E07u, 0x40201u) >> 18) & 31u;
-    const uint32_t o = (__umul24((y >> 6) & 0x1C0E07u, 0x40201u) >> 18) & 31u;
-    s.gno = g | (nn << 8) | (o << 16);
+    s.err = a0 + a1 + a2 - ((uint64_t)(y0 + y1 + y2) << 55);
+    // a 24-bit multiply by 1 + 2^9 + 2^18 puts three copies of the nine bits side by side; G/C/S of the first, N of the
+    // second and odd of the third lie 12 bits apart, and the three accumulators' fields (<= 6 each) add without carries
+    s.gno = (__umul24(y0, 0x40201u) & 0x07007007u) + (__umul24(y1, 0x40201u) & 0x07007007u) + (__umul24(y2, 0x40201u) & 0x07007007u);
     return s;
 }
 __device__ __forceinline__ uint32_t nl_nomatch(uint32_t v) {   // bit 7 of every byte that is NOT '\n' (other bits: anything)
     const uint32_t x = v ^ 0x0A0A0A0Au;
     return ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
 }
-__device__ __forceinline__ uint32_t f1_bytesum(const uint4& x) {
-    uint32_t q = __builtin_amdgcn_sad_u8(x.x, 0u, 0u);
+// bit k: byte k of the word is '\n'
+__device__ __forceinline__ uint32_t nl_nibble(uint32_t v) {
+    uint32_t t = (~nl_nomatch(v) & 0x80808080u) >> 7;   // bits 0, 8, 16, 24
+    t |= t >> 7;                                        // ... and 1, 9, 17
+    t |= t >> 14;                                       // ... and 2, 3
+    return t & 15u;
+}
+__device__ __forceinline__ uint32_t f1_bytesum(const uint4& x, uint32_t acc = 0u) {
+    uint32_t q = __builtin_amdgcn_sad_u8(x.x, 0u, acc);
     q = __builtin_amdgcn_sad_u8(x.y, 0u, q);
     q = __builtin_amdgcn_sad_u8(x.z, 0u, q);
     return __builtin_amdgcn_sad_u8(x.w, 0u, q);
-}
-__device__ __forceinline__ uint32_t f1_byte(const uint4& x, int i) {
-    const uint32_t w = i < 8 ? (i < 4 ? x.x : x.y) : (i < 12 ? x.z : x.w);
-    return (w >> (8 * (i & 3))) & 0xffu;
 }
 
 // The lane's vector at `pos` (16-byte aligned).  Bytes at and beyond n read as zero, except that a text whose last
 // byte is no '\n' gets one at position n: its last line then ends like every other (the chunk count covers position n).
 __device__ __forceinline__ uint4 f1_load(const uint8_t* __restrict__ text, uint64_t pos, uint64_t n, bool ends_nl) {
     if (pos + 16 <= n) return *reinterpret_cast<const uint4*>(text + pos);
-    uint32_t w[4] = {0, 0, 0, 0};
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     if (pos < n) {
         const uint4 v = *reinterpret_cast<const uint4*>(text + pos);   // the granule of an in-bounds byte lies in its page
         const int keep = (int)(n - pos);
         uint32_t m[4];
         range_masks(0, keep, m);
-        w[0] = v.x & m[0]; w[1] = v.y & m[1]; w[2] = v.z & m[2]; w[3] = v.w & m[3];
+        w0 = v.x & m[0]; w1 = v.y & m[1]; w2 = v.z & m[2]; w3 = v.w & m[3];
     }
     if (!ends_nl && pos <= n && n < pos + 16) {
         const int at = (int)(n - pos);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if ((at >> 2) == k) w[k] |= 0x0Au << (8 * (at & 3));
+        const uint32_t nl = 0x0Au << (8 * (at & 3));
+        w0 |= (at >> 2) == 0 ? nl : 0u; w1 |= (at >> 2) == 1 ? nl : 0u;
+        w2 |= (at >> 2) == 2 ? nl : 0u; w3 |= (at >> 2) == 3 ? nl : 0u;
     }
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    return make_uint4(w0, w1, w2, w3);
+}
+
+// The four bytes b - 2 .. b + 1 around byte b (0 .. 15) of the vector x, whose neighbours in the text are the words
+// `pre` (the four bytes in front of it) and `post` (the four behind it): two of the six words picked by compares and
+// one v_alignbyte, all in registers (indexing the vector as an array sends it through scratch memory).
+__device__ __forceinline__ uint32_t f1_window(uint32_t pre, const uint4& x, uint32_t post, int b) {
+    const int q = b + 2;            // offset of byte b - 2 in the 24-byte window
+    const int k = q >> 2;           // 0 .. 4
+    const uint32_t lo_a = (k & 1) ? x.x : pre, lo_b = (k & 1) ? x.z : x.y;
+    const uint32_t hi_a = (k & 1) ? x.y : x.x, hi_b = (k & 1) ? x.w : x.z;
+    uint32_t lo = (k & 2) ? lo_b : lo_a, hi = (k & 2) ? hi_b : hi_a;
+    lo = (k & 4) ? x.w : lo;
+    hi = (k & 4) ? post : hi;
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(q & 3));
 }
 
 // point = the running prefixes just in front of a line end, relative to the region's start (32 bytes):
@@ -117,8 +138,9 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
                                                        uint64_t* __restrict__ points, uint32_t cap_lines,
                                                        Fq1Region* __restrict__ regions) {
     __shared__ uint64_t lut2[256];
-    // the newline vectors of the chunk: the lane's running sums in front of each (error in two words, gno) and
-    // byte sum (15 bits) | the lane's newlines in front of it << 15 (8 bits) | lane * 8 + vector << 23
+    // the newline vectors of the chunk, each with the lane's running sums in front of it:
+    //   x, y: error sum (60 bits) | bits 6, 7 of the lane's newlines in front of it << 60;  z: gno
+    //   w: byte sum (16 bits) | lane * 16 + vector << 16 | bits 0 .. 5 of the newlines << 26
     __shared__ uint4 br[4][kFq1Cap];
     __shared__ uint4 bx[4][kFq1Keep];   // the first kFq1Keep of those vectors themselves (the others are read again)
     lut2[threadIdx.x] = lut2_entry(threadIdx.x, lut_g[threadIdx.x]);
@@ -135,43 +157,53 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
     uint64_t B_qb = 0, B_a = 0, B_b = 0;   // error sum = B_a + B_b * 2^48, B_a < 2^48
     bool over = false;
     for (uint64_t c = c0; c < c1; ++c) {
-        const uint64_t cb = c * kNlChunk;
-        uint4 vv[kFq1Vecs];
-        if (cb + kNlChunk <= n) {   // wave-uniform: all of the chunk lies in the text
-#pragma unroll
-            for (int j = 0; j < kFq1Vecs; ++j)
-                vv[j] = *reinterpret_cast<const uint4*>(text + cb + (uint64_t)lane * 128 + (uint64_t)j * 16);
-        } else {
-#pragma unroll
-            for (int j = 0; j < kFq1Vecs; ++j) vv[j] = f1_load(text, cb + (uint64_t)lane * 128 + (uint64_t)j * 16, n, ends_nl);
-        }
-        uint64_t r_err = 0;                       // the lane's running sums over its strip
-        uint32_t r_gno = 0, r_qb = 0, r_nl = 0;
+        const uint64_t cb = c * kFq1Chunk;
+        const bool inside = cb + kFq1Chunk <= n;   // wave-uniform: all of the chunk lies in the text
+        uint64_t r_err = 0;                       // the lane's running sums over its strip, in front of the vector at hand
+        uint32_t r_gno = 0, r_qb = 0, r_nl = 0;   // (r_gno: its last vector kept apart, so that no field of it passes 240)
+        uint32_t last_gno = 0;
         uint32_t ne = 0;                          // newline vectors of the chunk so far (wave-uniform)
+        for (int h = 0; h < 2; ++h) {
+            const uint64_t sb = cb + (uint64_t)lane * 256 + (uint64_t)h * 128;
+            uint4 vv[kFq1Vecs];
+            if (inside) {
 #pragma unroll
-        for (int j = 0; j < kFq1Vecs; ++j) {
-            const uint4& x = vv[j];
-            const F1Sums s = f1_sums(x, lut2);
-            // t: bit 7 of a byte is clear iff the byte is '\n'; the four words folded before the test
-            const uint32_t t0 = nl_nomatch(x.x), t1 = nl_nomatch(x.y), t2 = nl_nomatch(x.z), t3 = nl_nomatch(x.w);
-            const uint32_t any = ~(t0 & t1 & t2 & t3) & 0x80808080u;
-            const uint64_t ball = __ballot(any != 0);
-            if (ball) {
-                const uint32_t at = ne + __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
-                if (any != 0) {   // at < 512: a chunk has 512 vectors
-                    br[wib][at] = make_uint4((uint32_t)r_err, (uint32_t)(r_err >> 32), r_gno,
-                                             r_qb | (r_nl << 15) | ((uint32_t)(lane * 8 + j) << 23));
-                    if (at < (uint32_t)kFq1Keep) bx[wib][at] = x;
-                }
-                ne += (uint32_t)__popcll(ball);
-                r_nl += __popc(((~t0 & 0x80808080u) >> 7) | ((~t1 & 0x80808080u) >> 6) | ((~t2 & 0x80808080u) >> 5) | ((~t3 & 0x80808080u) >> 4));
+                for (int j = 0; j < kFq1Vecs; ++j) vv[j] = *reinterpret_cast<const uint4*>(text + sb + (uint64_t)j * 16);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kFq1Vecs; ++j) vv[j] = f1_load(text, sb + (uint64_t)j * 16, n, ends_nl);
             }
-            r_err += s.err; r_gno += s.gno; r_qb += f1_bytesum(x);
+#pragma unroll
+            for (int j = 0; j < kFq1Vecs; ++j) {
+                const uint4& x = vv[j];
+                const F1Sums s = f1_sums(x, lut2);
+                r_gno += last_gno;
+                // t: bit 7 of a byte is clear iff the byte is '\n'; the four words folded before the test
+                const uint32_t t0 = nl_nomatch(x.x), t1 = nl_nomatch(x.y), t2 = nl_nomatch(x.z), t3 = nl_nomatch(x.w);
+                const uint32_t any = ~(t0 & t1 & t2 & t3) & 0x80808080u;
+                const uint64_t ball = __ballot(any != 0);
+                if (ball) {
+                    const uint32_t at = ne + __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
+                    if (any != 0) {
+                        if (at < (uint32_t)kFq1Cap) {
+                            br[wib][at] = make_uint4((uint32_t)r_err, (uint32_t)(r_err >> 32) | ((r_nl >> 6) << 28), r_gno,
+                                                     r_qb | ((uint32_t)(lane * 16 + h * 8 + j) << 16) | ((r_nl & 63u) << 26));
+                            if (at < (uint32_t)kFq1Keep) bx[wib][at] = x;
+                        } else {
+                            over = true;
+                        }
+                    }
+                    ne += (uint32_t)__popcll(ball);
+                    r_nl += __popc(((~t0 & 0x80808080u) >> 7) | ((~t1 & 0x80808080u) >> 6) | ((~t2 & 0x80808080u) >> 5) | ((~t3 & 0x80808080u) >> 4));
+                }
+                r_err += s.err; last_gno = s.gno; r_qb = f1_bytesum(x, r_qb);
+            }
         }
-        // join the lanes: six inclusive scans of the lane totals (every partial sum fits 32 bits: 128 bytes per lane)
-        const uint32_t o1 = (r_gno & 0xFFu) | (((r_gno >> 8) & 0xFFu) << 16);                 // G/C/S | N << 16
-        const uint32_t o2 = r_qb;                                                             // byte sum
-        const uint32_t o3 = ((r_gno >> 16) & 0xFFu) | (r_nl << 16);                           // odd | newlines << 16
+        if (ne > (uint32_t)kFq1Cap) ne = kFq1Cap;   // (the region is flagged: its points will not be used)
+        // join the lanes: six inclusive scans of the lane totals (every partial sum fits 32 bits: 256 bytes per lane)
+        const uint32_t o1 = (gno_g(r_gno) + gno_g(last_gno)) | ((gno_n(r_gno) + gno_n(last_gno)) << 16);   // G/C/S | N << 16
+        const uint32_t o2 = r_qb;                                                                        // byte sum
+        const uint32_t o3 = (gno_o(r_gno) + gno_o(last_gno)) | (r_nl << 16);                              // odd | newlines << 16
         const uint32_t o4 = (uint32_t)r_err & 0x3FFFFFFu, o5 = (uint32_t)(r_err >> 26) & 0x3FFFFFFu, o6 = (uint32_t)(r_err >> 52);
         const uint32_t i1 = wave_scan_incl_u32(o1), i2 = wave_scan_incl_u32(o2), i3 = wave_scan_incl_u32(o3);
         const uint32_t i4 = wave_scan_incl_u32(o4), i5 = wave_scan_incl_u32(o5), i6 = wave_scan_incl_u32(o6);
@@ -180,65 +212,70 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
             const bool live = eb + (uint32_t)lane < ne;
             uint4 x = make_uint4(0, 0, 0, 0), rr = make_uint4(0, 0, 0, 0);
             if (live) rr = br[wib][eb + lane];
-            const uint32_t vi = rr.w >> 23;
+            const uint32_t vi = (rr.w >> 16) & 0x3FFu;
+            const uint64_t gpos0 = cb + (uint64_t)vi * 16;
+            uint32_t pre = 0x78787878u, post = 0;   // the text around the vector ('x': no white space in front of the text)
             if (live) {
                 if (eb + (uint32_t)lane < (uint32_t)kFq1Keep) x = bx[wib][eb + lane];
-                else x = f1_load(text, cb + (uint64_t)vi * 16, n, ends_nl);   // a cache hit, mostly: the wave has just read it
+                else x = f1_load(text, gpos0, n, ends_nl);   // a cache hit, mostly: the wave has just read it
+                if (gpos0 >= 4) pre = *reinterpret_cast<const uint32_t*>(text + gpos0 - 4);
+                if (gpos0 + 20 <= n) post = *reinterpret_cast<const uint32_t*>(text + gpos0 + 16);
+                else if (gpos0 + 16 < n) post = (uint32_t)text[gpos0 + 16];   // its first byte is all that is looked at
             }
-            const int src = (int)(vi >> 3);   // the lane that owns the vector
+            const int src = (int)(vi >> 4);   // the lane that owns the vector
             const uint32_t e1 = (uint32_t)__shfl((int)(i1 - o1), src), e2 = (uint32_t)__shfl((int)(i2 - o2), src);
             const uint32_t e3 = (uint32_t)__shfl((int)(i3 - o3), src), e4 = (uint32_t)__shfl((int)(i4 - o4), src);
             const uint32_t e5 = (uint32_t)__shfl((int)(i5 - o5), src), e6 = (uint32_t)__shfl((int)(i6 - o6), src);
-            const uint32_t gcs0 = B_gcs + (e1 & 0xFFFFu) + (rr.z & 0xFFu), n0 = B_n + (e1 >> 16) + ((rr.z >> 8) & 0xFFu);
-            const uint32_t odd0 = B_odd + (e3 & 0xFFFFu) + ((rr.z >> 16) & 0xFFu);
-            uint32_t line = B_lines + (e3 >> 16) + ((rr.w >> 15) & 0xFFu);
-            const uint64_t qb0 = B_qb + e2 + (rr.w & 0x7FFFu);
-            const uint64_t sum0 = B_a + e4 + ((uint64_t)e5 << 26) + (((uint64_t)rr.y << 32) | rr.x);   // < 2^61
+            const uint32_t gcs0 = B_gcs + (e1 & 0xFFFFu) + gno_g(rr.z), n0 = B_n + (e1 >> 16) + gno_n(rr.z);
+            const uint32_t odd0 = B_odd + (e3 & 0xFFFFu) + gno_o(rr.z);
+            uint32_t line = B_lines + (e3 >> 16) + ((rr.w >> 26) | ((rr.y >> 28) << 6));
+            const uint64_t qb0 = B_qb + e2 + (rr.w & 0xFFFFu);
+            const uint64_t sum0 = B_a + e4 + ((uint64_t)e5 << 26) + (((uint64_t)(rr.y & 0x0FFFFFFFu) << 32) | rr.x);   // < 2^62
             const uint64_t bb0 = B_b + ((uint64_t)e6 << 4);
-            const uint32_t rel0 = (uint32_t)(c - c0) * kNlChunk + vi * 16;
-            const uint64_t gpos0 = cb + (uint64_t)vi * 16;
-            uint32_t bits = live ? vec_nl_bits(x, 16) : 0u;
+            const uint32_t rel0 = (uint32_t)(c - c0) * kFq1Chunk + vi * 16;
+            uint32_t bits = nl_nibble(x.x) | (nl_nibble(x.y) << 4) | (nl_nibble(x.z) << 8) | (nl_nibble(x.w) << 12);
+            if (!live) bits = 0;
             // sums of the vector's bytes in front of the newline at hand: from a masked lookup of the whole vector for
-            // its first newline, for a further one a few bytes on ("\n+\n") by adding those bytes
+            // its first newline, for a further one up to three bytes on ("\n+\n") by adding the bytes between
             int pb = -1;
             uint64_t perr = 0;
-            uint32_t pgcs = 0, pn = 0, podd = 0, pqb = 0;
+            uint32_t pgno = 0, pqb = 0;
             while (__ballot(bits != 0) != 0) {
                 if (bits != 0) {
                     const int b = __ffs((int)bits) - 1;
                     bits &= bits - 1;
-                    if (pb < 0 || b - pb > 4) {
+                    const uint32_t win = f1_window(pre, x, post, b);   // bytes b - 2, b - 1, b ('\n'), b + 1
+                    const uint32_t prev2 = win & 0xFFu, prev = (win >> 8) & 0xFFu, next = win >> 24;
+                    if (pb < 0 || b - pb > 3) {
                         uint32_t m[4];
                         range_masks(0, b, m);
                         const uint4 xm = make_uint4(x.x & m[0], x.y & m[1], x.z & m[2], x.w & m[3]);
                         const F1Sums p = f1_sums(xm, lut2);   // the 16 - b zeroed bytes count as odd
-                        perr = p.err; pgcs = p.gno & 0xFFu; pn = (p.gno >> 8) & 0xFFu;
-                        podd = ((p.gno >> 16) & 0xFFu) - (uint32_t)(16 - b);
+                        perr = p.err; pgno = p.gno - ((uint32_t)(16 - b) << 24);
                         pqb = f1_bytesum(xm);
                     } else {
-                        podd += 1; pqb += '\n';   // the newline at pb
-                        for (int t = pb + 1; t < b; ++t) {
-                            const uint32_t c = f1_byte(x, t);
-                            const uint64_t v = lut2[c];
-                            perr += v & kF1Err; pgcs += (uint32_t)(v >> kF1Gcs) & 1u; pn += (uint32_t)(v >> kF1N) & 1u;
-                            podd += (uint32_t)(v >> kF1Odd) & 1u; pqb += c;
+                        pgno += 1u << 24; pqb += '\n';   // the newline at pb
+                        if (b - pb == 3) {
+                            const uint64_t v = lut2[prev2];
+                            const uint32_t y = (uint32_t)(v >> 55);
+                            perr += v & kF1Err; pgno += __umul24(y, 0x40201u) & 0x07007007u; pqb += prev2;
+                        }
+                        if (b - pb >= 2) {
+                            const uint64_t v = lut2[prev];
+                            const uint32_t y = (uint32_t)(v >> 55);
+                            perr += v & kF1Err; pgno += __umul24(y, 0x40201u) & 0x07007007u; pqb += prev;
                         }
                     }
                     pb = b;
-                    const uint64_t gpos = gpos0 + (uint64_t)b;
                     // the bytes around the line end
-                    uint32_t prev = 'x', next = 0;
-                    if (b >= 1) prev = f1_byte(x, b - 1);
-                    else if (gpos > 0) prev = text[gpos - 1];
-                    if (gpos + 1 < n) next = b < 15 ? f1_byte(x, b + 1) : (uint32_t)text[gpos + 1];
                     uint32_t tw = 0;
-                    if (is_space((uint8_t)prev)) tw = (prev == '\r' && b >= 2 && !is_space((uint8_t)f1_byte(x, b - 2))) ? 1u : 3u;
+                    if (is_space((uint8_t)prev)) tw = (prev == '\r' && b >= 2 && !is_space((uint8_t)prev2)) ? 1u : 3u;
                     const uint32_t cls = next == '@' ? 1u : (next == '+' ? 2u : 0u);
                     const uint64_t S = sum0 + perr;
                     const uint64_t q0 = (S & kM48) | ((uint64_t)cls << 48) | ((uint64_t)tw << 50);
                     const uint64_t q1 = ((bb0 + (S >> 48)) & 0xFFFFFFFFull) | ((qb0 + pqb) << 32);
-                    const uint64_t q2 = (uint64_t)(gcs0 + pgcs) | ((uint64_t)(n0 + pn) << 24);
-                    const uint64_t q3 = (uint64_t)(odd0 + podd) | ((uint64_t)(rel0 + (uint32_t)b) << 24);
+                    const uint64_t q2 = (uint64_t)(gcs0 + gno_g(pgno)) | ((uint64_t)(n0 + gno_n(pgno)) << 24);
+                    const uint64_t q3 = (uint64_t)(odd0 + gno_o(pgno)) | ((uint64_t)(rel0 + (uint32_t)b) << 24);
                     if (line < cap_lines) {
                         ulonglong2* o = reinterpret_cast<ulonglong2*>(out + (uint64_t)line * 4);
                         o[0] = make_ulonglong2(q0, q1);
@@ -678,7 +715,7 @@ __global__ __launch_bounds__(256) void fq1_finalize_kernel(const uint8_t* __rest
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------------
-uint64_t fq1_chunks(uint64_t n) { return n / kNlChunk + 1; }   // position n lies in the last chunk
+uint64_t fq1_chunks(uint64_t n) { return n / kFq1Chunk + 1; }   // position n lies in the last chunk
 void fq1_shape(uint64_t n, int want_regions, uint32_t* cpr, uint64_t* n_regions) {
     const uint64_t n_chunks = fq1_chunks(n);
     uint64_t want = want_regions > 0 ? (uint64_t)want_regions : 4096;
@@ -704,7 +741,7 @@ hipError_t launch_fq1_finalize(const uint8_t* text, uint64_t n, uint64_t n_recor
                                const Fq1Index& ix, hipStream_t s) {
     if (n_records == 0) return hipSuccess;
     hipLaunchKernelGGL(fq1_finalize_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n,
-                       n_records, f.points, f.regions, n_regions, cpr * kFq1LinesPerChunk, (uint64_t)cpr * kNlChunk, ra,
+                       n_records, f.points, f.regions, n_regions, cpr * kFq1LinesPerChunk, (uint64_t)cpr * kFq1Chunk, ra,
                        read_base, lut_dev, thr, mux, errors, n_channels, gate,
                        (float)((double)n_regions / (4.0 * (double)n_records)), ix);
     return hipGetLastError();

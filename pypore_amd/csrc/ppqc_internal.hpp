@@ -235,8 +235,9 @@ hipError_t launch_fastq_finalize(const uint8_t* text, uint64_t n, uint64_t n_rec
                                  hipStream_t s, bool whole_lines = false);   // also lens32, the sort gate and (ix) hours and cells
 
 // ---- FASTQ text of short lines in one pass (ppqc_fastq1.hip) ---------------------------------------------------------
-constexpr uint32_t kFq1LinesPerChunk = 64;       // share of the point table per 8 KiB chunk of a region (lines)
-constexpr uint64_t kFq1MaxRegionChunks = 2048;   // a region holds at most 2^24 bytes (24-bit positions in the points)
+constexpr uint32_t kFq1Chunk = 16384;            // bytes of text a wave of fq1_scan_kernel takes at a time (256 per lane)
+constexpr uint32_t kFq1LinesPerChunk = 128;      // share of the point table per chunk of a region (lines)
+constexpr uint64_t kFq1MaxRegionChunks = 1024;   // a region holds at most 2^24 bytes (24-bit positions in the points)
 struct Fq1Region { uint64_t lines, gcs, n, odd, qb, err_a, err_b, flags; };   // totals, then exclusive prefix over the regions
 struct Fq1Scratch {
     uint64_t* points;      // 4 words per line end, kFq1LinesPerChunk per chunk
