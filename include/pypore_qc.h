@@ -364,12 +364,14 @@ int ppqc_bind_thread(ppqc_ctx* ctx);
  * new context -- and other values force one path for this context: "tile_dense" 0|1, "dense_len" bytes, "tile_all" 0|1,
  * "tile_shift" 12..16, "pre" 0|1, "fastq_sums" 0|1|2, "fastq_hdr_aux" 0|1|2, "fastq_one_pass" 0|1, "fq1_regions" n,
  * "sort_beside" 0|1, "n50_select" 0|1 (the local N50 by sort / by radix select), "fastq_index_aux" 0|1 (the extremes of a
- * FASTQ text's reads in line / beside the tables) (pypore_amd/csrc/ppqc_internal.hpp, Tuning).  Results never depend on it (the parity tests run the paths against each
+ * FASTQ text's reads in line / beside the tables), "fq1_early" 0|1 (the one-pass finalize kernel launched when the host
+ * knows the line count / straight behind the scan) (pypore_amd/csrc/ppqc_internal.hpp, Tuning).  Results never depend on it (the parity tests run the paths against each
  * other); the library reads no environment variable. */
 int ppqc_set_tuning(ppqc_ctx* ctx, const char* name, int value);
 /* No counterpart in the reference.  Counters of the same code paths, for the tests that must know which one ran:
  * "fastq_one_pass" texts that went through the one-pass kernels, "fastq_declined" texts those kernels handed to the
- * general path, "fastq_general" texts the general path took (ppqc_submit_fastq[_device], since ppqc_create). */
+ * general path, "fastq_general" texts the general path took, "fastq_early" one-pass texts whose finalize kernel ran
+ * from the launch made before the line count was known (ppqc_submit_fastq[_device], since ppqc_create). */
 int ppqc_path_count(ppqc_ctx* ctx, const char* name, uint64_t* out);
 
 /* Several GPUs driven by ONE process, without torch: the counterpart of gathering the workers' results over the result

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -196,7 +197,8 @@ struct ppqc_ctx {
     uint64_t cap_chunks = 0, cap_lines = 0;
     Fq1Scratch fq1{};           // the one-pass kernels (ppqc_fastq1.hip)
     uint64_t cap_fq1_lines = 0, cap_fq1_regions = 0;
-    uint64_t n_fq1 = 0, n_fq1_declined = 0, n_fq_general = 0;   // ppqc_path_count
+    uint64_t n_fq1 = 0, n_fq1_declined = 0, n_fq_general = 0, n_fq1_early = 0;   // ppqc_path_count
+    uint64_t fq1_ticket = 0;      // launches of the one-pass scan so far (the regions kernel hands the newest back, run_fastq_one_pass)
     int64_t fq_line_hint = -1;  // mean bytes per line of the last FASTQ text (-1: none yet); a hint for the scan pass only
 
     std::vector<EvPair> pending;
@@ -446,6 +448,7 @@ static int create_impl(ppqc_ctx* c, int device, const ppqc_config* cfg) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->ev_reads));
     HIPCHK(hipHostMalloc((void**)&c->maxlen_host, 64, hipHostMallocDefault));
+    memset(c->maxlen_host, 0, 64);   // (the ticket word: pinned memory comes back as the last owner left it)
 
     // error-probability LUT: e[b] = round(2^52 * 10^(-q/10)), q = clamp(b - 33, 0, 93)
     uint64_t lut[256];
@@ -796,6 +799,24 @@ static int fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_reco
     return PPQC_OK;
 }
 
+// Waits until a kernel on `s` has stored `want` in the pinned word *w (a release store at system scope behind the data
+// it announces).  Now and then the stream is asked whether it has ended without the word: a failed launch or a fault.
+static int wait_pinned_word(const uint64_t* w, uint64_t want, hipStream_t s) {
+    const volatile uint64_t* vw = w;
+    for (uint64_t spin = 1;; ++spin) {
+        if (*vw == want) break;
+        if ((spin & 0xFFFF) == 0) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e == hipErrorNotReady) continue;
+            if (e != hipSuccess) return fail(PPQC_E_HIP, std::string("while waiting for the FASTQ scan: ") + hipGetErrorString(e));
+            if (*vw == want) break;
+            return fail(PPQC_E_HIP, "the FASTQ scan ended without handing its line count to the host");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return PPQC_OK;
+}
+
 static int fastq_line_count_error(uint64_t n_lines) {
     return fail(PPQC_E_INVALID, "FASTQ text has " + std::to_string(n_lines) + " lines, not a multiple of 4 (blank "
                                     "lines or multi-line records: use ppqc_fastq_scan / ppqc_fastq_pack)");
@@ -820,10 +841,40 @@ static int run_fastq_one_pass(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint
         c->cap_fq1_regions = n_regions + 64;
     }
     if (!c->fq1.head) CHK(grow(&c->fq1.head, 0, 2, s));
-    uint64_t* h = c->maxlen_host;   // pinned scratch words: [1] lines, [2] flags
-    HIPCHK(launch_fq1_scan(text, n, c->fq1, cpr, n_regions, c->lut_dev, h + 1, s));
-    HIPCHK(hipEventRecord(c->ev_fq, s));
-    HIPCHK(hipEventSynchronize(c->ev_fq));
+    uint64_t* h = c->maxlen_host;   // pinned scratch words: [1] lines, [2] flags, [5] the ticket of the launch they belong to
+    // No event behind the regions kernel: an event record between two kernels of a stream costs the second one some 20 us
+    // here, and the finalize kernel may follow at once (below).  The host polls the ticket word instead.
+    const uint64_t ticket = ++c->fq1_ticket;
+    HIPCHK(launch_fq1_scan(text, n, c->fq1, cpr, n_regions, c->lut_dev, h + 1, ticket, s));
+    // The index-only results of these reads with the finalize kernel, as a CSR batch leaves them when it is submitted
+    // (run_batch): the finalize then needs no extremes kernel and the tables no cell atomics.
+    const bool pre = c->pre_ok && c->res_clean && c->cfg.time_mode == 0 && c->tn.pre != 0;
+    // The finalize kernel straight behind the scan, before the line count has come back (the GPU would wait some 30 us
+    // for the host's answer): the last text's mean line length says about how many records there are; if the arrays
+    // hold a few more than that, the kernel takes the count from the regions kernel's words and goes ahead unless it
+    // finds the text declined, its lines no multiple of four, or more records than `room` -- the very tests the host
+    // makes below on the same words, so both know whether it ran.
+    uint64_t room = 0;
+    bool early = false, early_cells = false;
+    if (c->tn.fq1_early != 0 && c->fq_line_hint > 0) {
+        const uint64_t guess = n / (4 * (uint64_t)c->fq_line_hint) + 1;
+        room = c->cap_reads > c->n_reads ? c->cap_reads - c->n_reads : 0;
+        if (room >= (1ull << 30)) room = (1ull << 30) - 1;
+        early_cells = pre && c->cells_early && cmh_packable(c->n_reads + 1, c->bases_total + n);
+        if (early_cells) {   // the packed cells hold 2^24 - 1 reads
+            const uint64_t fit = (1ull << (64 - kCmhShift)) - 1 - c->n_reads;
+            if (room > fit) room = fit;
+        }
+        if (room >= guess + guess / 16) {
+            room = guess + guess / 16;   // a thread per record it may hold: 6 % of them idle when the guess is right
+            Fq1Index ix{pre ? 1 : 0, c->tp, early_cells ? c->sum_buf + c->tp.lay.off_cmh_bases : nullptr};
+            HIPCHK(launch_fq1_finalize_early(text, n, room, c->fq1, cpr, n_regions, c->ra, c->n_reads, c->lut_dev,
+                                             c->qthr, mux, c->res_buf + c->res_words, c->cfg.n_channels,
+                                             c->res_buf + c->res_words + 8, ix, s));
+            early = true;
+        }
+    }
+    CHK(wait_pinned_word(h + 5, ticket, s));
     const uint64_t n_lines = h[1];
     c->fq_line_hint = n_lines ? (int64_t)(n / n_lines) : -1;
     if (h[2] != 0) { ++c->n_fq1_declined; return PPQC_OK; }
@@ -831,15 +882,16 @@ static int run_fastq_one_pass(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint
     if (n_lines % 4 != 0) return fastq_line_count_error(n_lines);
     const uint64_t R = n_lines / 4;
     if (R >= (1ull << 30)) return fail(PPQC_E_RANGE, "more than 2^30-1 records in one text");
+    *done = true;
+    if (early && R <= room) {   // the kernel is running, or done
+        ++c->n_fq1_early;
+        return fastq_committed(c, R, n, n_records, true, pre, early_cells);
+    }
     CHK(ensure_reads(c, c->n_reads + R));
-    // The index-only results of these reads with the same kernel, as a CSR batch leaves them when it is submitted
-    // (run_batch): the finalize then needs no extremes kernel and the tables no cell atomics.
-    const bool pre = c->pre_ok && c->res_clean && c->cfg.time_mode == 0 && c->tn.pre != 0;
     const bool cells = pre && c->cells_early && cmh_packable(c->n_reads + R, c->bases_total + n);
     Fq1Index ix{pre ? 1 : 0, c->tp, cells ? c->sum_buf + c->tp.lay.off_cmh_bases : nullptr};
     HIPCHK(launch_fq1_finalize(text, n, R, c->fq1, cpr, n_regions, c->ra, c->n_reads, c->lut_dev, c->qthr, mux,
                                c->res_buf + c->res_words, c->cfg.n_channels, c->res_buf + c->res_words + 8, ix, s));
-    *done = true;
     return fastq_committed(c, R, n, n_records, true, pre, cells);
 }
 
@@ -1232,7 +1284,7 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
     const bool from_gate = c->index_pending && c->pre_run && c->gate_max_run;
     if (!from_gate) CHK(join_index(c));
     HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, from_gate ? c->res_buf + c->res_words + 8 : c->max_buf,
-                         from_gate ? kGateWords : 1, c->tab_slab, s, cell_mode, c->cc_ready ? c->cc : nullptr));
+                         from_gate ? kGateWords : 1, c->tab_slab, s, cell_mode, c->cc_ready ? c->cc : nullptr, from_gate));
     c->state = 2;
     if (c->n50_early) {   // the N50 is there already (ppqc_n50_select_early): the finalize ends here
         HIPCHK(hipEventRecord(c->ev_t1, s));
@@ -1330,9 +1382,9 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     uint64_t* host_out = early_out ? c->res_host + c->res_words + 7 : nullptr;
     if (by_select) {
         for (int r = 0; r < 3; ++r) {
-            HIPCHK(launch_select_hist(dlens, n, kSelShift[r], kSelBits[r], c->sel_state, c->sel_buf, ss));
+            HIPCHK(launch_select_hist(dlens, n, kSelShift[r], kSelBits[r], c->sel_state, c->sel_buf, ss, gate, gate_words));
             HIPCHK(launch_select_pick(c->sel_buf, nullptr, c->sel_state, kSelShift[r], kSelBits[r], r == 2, r == 0,
-                                      c->n50_out, host_out, ss));
+                                      c->n50_out, host_out, ss, gate, gate_words));
         }
     } else if (pre) {
         HIPCHK(hipEventSynchronize(c->ev_pre));   // a wait of the host while the GPU is busy with the tile kernel
@@ -1605,7 +1657,7 @@ int ppqc_set_tuning(ppqc_ctx* c, const char* name, int value) {
         {"tile_all", &c->tn.tile_all, -1, 1},           {"tile_shift", &c->tn.tile_shift, -1, kMaxTileShift},
         {"pre", &c->tn.pre, -1, 1},                     {"fastq_sums", &c->tn.fastq_sums, -1, 2},
         {"fastq_hdr_aux", &c->tn.fastq_hdr_aux, -1, 2}, {"sort_beside", &c->tn.sort_beside, -1, 1},
-        {"n50_select", &c->tn.n50_select, -1, 1}, {"fastq_index_aux", &c->tn.fastq_index_aux, -1, 1},
+        {"n50_select", &c->tn.n50_select, -1, 1}, {"fq1_early", &c->tn.fq1_early, -1, 1}, {"fastq_index_aux", &c->tn.fastq_index_aux, -1, 1},
         {"fastq_one_pass", &c->tn.fastq_one_pass, -1, 1}, {"fq1_regions", &c->tn.fq1_regions, -1, 1 << 20},
     };
     for (auto& k : knobs)
@@ -1622,6 +1674,7 @@ int ppqc_path_count(ppqc_ctx* c, const char* name, uint64_t* out) {
     if (!c || !name || !out) return fail(PPQC_E_INVALID, "null argument");
     if (strcmp(name, "fastq_one_pass") == 0) *out = c->n_fq1;
     else if (strcmp(name, "fastq_declined") == 0) *out = c->n_fq1_declined;
+    else if (strcmp(name, "fastq_early") == 0) *out = c->n_fq1_early;
     else if (strcmp(name, "fastq_general") == 0) *out = c->n_fq_general;
     else return fail(PPQC_E_INVALID, std::string("ppqc_path_count: unknown counter ") + name);
     return PPQC_OK;

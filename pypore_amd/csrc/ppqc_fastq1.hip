@@ -306,13 +306,15 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
 }
 
 // Single block: regions[k] becomes the exclusive prefix of the regions' totals; head = {lines of the text, OR of the
-// flags}, also to the pinned words the host waits for.  Every thread adds up a run of regions, a Hillis-Steele scan in
-// LDS joins the 1024 runs field by field (the error sum's low part as a plain sum: 2^15 regions of 2^48 at most).
-constexpr int kRegThreads = 1024;
+// flags}, also to the pinned words the host waits for.  Every thread adds up a run of regions; each wave scans its 64
+// runs with shuffles, field by field, and one barrier joins the eight waves (the error sum's low part as a plain sum:
+// 2^15 regions of 2^48 at most).
+constexpr int kRegThreads = 512;   // eight waves: room for 256 registers each (eight 64-bit fields, their loads in flight)
 __global__ __launch_bounds__(kRegThreads) void fq1_regions_kernel(Fq1Region* __restrict__ regions, uint64_t n_regions,
-                                                                  uint64_t* __restrict__ head, uint64_t* __restrict__ host_out) {
-    __shared__ uint64_t sh[8][kRegThreads];
-    const uint32_t t = threadIdx.x;
+                                                                  uint64_t* __restrict__ head, uint64_t* __restrict__ host_out,
+                                                                  uint64_t ticket) {
+    __shared__ uint64_t wsum[8][kRegThreads / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
     const uint64_t seg = (n_regions + kRegThreads - 1) / kRegThreads;
     const uint64_t b = t * seg < n_regions ? t * seg : n_regions, e = b + seg < n_regions ? b + seg : n_regions;
     uint64_t tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // lines, gcs, n, odd, qb, err_a, err_b, flags
@@ -323,24 +325,37 @@ __global__ __launch_bounds__(kRegThreads) void fq1_regions_kernel(Fq1Region* __r
     }
     uint64_t run[8];
 #pragma unroll
-    for (int f = 0; f < 8; ++f) { run[f] = tot[f]; sh[f][t] = tot[f]; }
-    __syncthreads();
-    for (uint32_t o = 1; o < (uint32_t)kRegThreads; o <<= 1) {   // all eight fields in step
-        uint64_t x[8];
+    for (int f = 0; f < 8; ++f) run[f] = tot[f];
 #pragma unroll
-        for (int f = 0; f < 8; ++f) x[f] = t >= o ? sh[f][t - o] : 0;
-        __syncthreads();
+    for (uint32_t o = 1; o < 64; o <<= 1) {
 #pragma unroll
-        for (int f = 0; f < 8; ++f) { run[f] = f == 7 ? (run[f] | x[f]) : run[f] + x[f]; sh[f][t] = run[f]; }
-        __syncthreads();
+        for (int f = 0; f < 8; ++f) {
+            const uint64_t x = __shfl_up((unsigned long long)run[f], o);
+            if (lane >= o) run[f] = f == 7 ? (run[f] | x) : run[f] + x;
+        }
     }
+    if (lane == 63) {
 #pragma unroll
-    for (int f = 0; f < 7; ++f) run[f] -= tot[f];   // exclusive (the flags: inclusive, only the last thread's are used)
+        for (int f = 0; f < 8; ++f) wsum[f][w] = run[f];
+    }
+    __syncthreads();
+    uint64_t all_flags = 0;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+        uint64_t before = 0;
+        for (uint32_t k = 0; k < (uint32_t)(kRegThreads / 64); ++k) {
+            const uint64_t x = wsum[f][k];
+            if (f == 7) all_flags |= x;
+            else if (k < w) before += x;
+        }
+        if (f < 7) run[f] += before - tot[f];   // exclusive
+    }
     if (t == kRegThreads - 1) {
-        head[0] = run[0] + tot[0]; head[1] = run[7];
-        if (host_out) {
-            host_out[0] = run[0] + tot[0]; host_out[1] = run[7];
+        head[0] = run[0] + tot[0]; head[1] = all_flags;
+        if (host_out) {   // pinned words the host polls: the two results, then (behind a fence) this launch's ticket
+            host_out[0] = run[0] + tot[0]; host_out[1] = all_flags;
             __threadfence_system();
+            __hip_atomic_store(&host_out[4], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     for (uint64_t i = b; i < e; ++i) {
@@ -598,8 +613,18 @@ __global__ __launch_bounds__(256) void fq1_finalize_kernel(const uint8_t* __rest
                                                            uint64_t read_base, const uint64_t* __restrict__ lut_g,
                                                            QThr thr, uint8_t mux, uint64_t* __restrict__ errors,
                                                            uint32_t n_channels, uint64_t* __restrict__ gate,
-                                                           float reg_per_line, Fq1Index ix) {
+                                                           float reg_per_line, Fq1Index ix,
+                                                           const uint64_t* __restrict__ head, uint64_t max_records) {
     __shared__ unsigned int s_mis, s_bad, s_max;
+    if (head != nullptr) {
+        // launched before the host knew the text's lines (launch_fq1_finalize_early): the count comes from the regions
+        // kernel's words, and a text the host will not commit as it stands (declined by the scan, lines that are no
+        // records, more records than the arrays hold) is left alone -- the host sees the same words and does the rest
+        const uint64_t lines = head[0];
+        if (head[1] != 0 || (lines & 3u) != 0 || (lines >> 2) > max_records) return;
+        n_records = lines >> 2;
+        reg_per_line = (float)n_regions / (float)(lines ? lines : 1);
+    }
     if (threadIdx.x == 0) { s_mis = 0; s_bad = 0; s_max = 0; }
     __syncthreads();
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -727,11 +752,11 @@ void fq1_shape(uint64_t n, int want_regions, uint32_t* cpr, uint64_t* n_regions)
 }
 
 hipError_t launch_fq1_scan(const uint8_t* text, uint64_t n, const Fq1Scratch& f, uint32_t cpr, uint64_t n_regions,
-                           const uint64_t* lut_dev, uint64_t* host_out, hipStream_t s) {
+                           const uint64_t* lut_dev, uint64_t* host_out, uint64_t ticket, hipStream_t s) {
     const uint64_t n_chunks = fq1_chunks(n);
     hipLaunchKernelGGL(fq1_scan_kernel, dim3((unsigned)((n_regions + 3) / 4)), dim3(256), 0, s, text, n, n_chunks, cpr, lut_dev,
                        f.points, cpr * kFq1LinesPerChunk, f.regions);
-    hipLaunchKernelGGL(fq1_regions_kernel, dim3(1), dim3(kRegThreads), 0, s, f.regions, n_regions, f.head, host_out);
+    hipLaunchKernelGGL(fq1_regions_kernel, dim3(1), dim3(kRegThreads), 0, s, f.regions, n_regions, f.head, host_out, ticket);
     return hipGetLastError();
 }
 
@@ -743,7 +768,21 @@ hipError_t launch_fq1_finalize(const uint8_t* text, uint64_t n, uint64_t n_recor
     hipLaunchKernelGGL(fq1_finalize_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n,
                        n_records, f.points, f.regions, n_regions, cpr * kFq1LinesPerChunk, (uint64_t)cpr * kFq1Chunk, ra,
                        read_base, lut_dev, thr, mux, errors, n_channels, gate,
-                       (float)((double)n_regions / (4.0 * (double)n_records)), ix);
+                       (float)((double)n_regions / (4.0 * (double)n_records)), ix, (const uint64_t*)nullptr, (uint64_t)0);
+    return hipGetLastError();
+}
+
+// The same, enqueued straight behind the regions kernel, before the host has seen the line count: the grid is sized for
+// max_records records (a thread each), f.head tells the kernel how many there are, and it does nothing unless the text is
+// one the host will commit with at most max_records records (the host applies the same test to the same words).
+hipError_t launch_fq1_finalize_early(const uint8_t* text, uint64_t n, uint64_t max_records, const Fq1Scratch& f, uint32_t cpr, uint64_t n_regions, ReadArrays ra,
+                                     uint64_t read_base, const uint64_t* lut_dev, const QThr& thr, uint8_t mux,
+                                     uint64_t* errors, uint32_t n_channels, uint64_t* gate, const Fq1Index& ix,
+                                     hipStream_t s) {
+    if (max_records == 0) return hipSuccess;
+    hipLaunchKernelGGL(fq1_finalize_kernel, dim3((unsigned)((max_records + 255) / 256)), dim3(256), 0, s, text, n,
+                       (uint64_t)0, f.points, f.regions, n_regions, cpr * kFq1LinesPerChunk, (uint64_t)cpr * kFq1Chunk, ra,
+                       read_base, lut_dev, thr, mux, errors, n_channels, gate, 0.0f, ix, (const uint64_t*)f.head, max_records);
     return hipGetLastError();
 }
 

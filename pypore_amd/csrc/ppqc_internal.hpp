@@ -107,6 +107,8 @@ struct Tuning {
     int fastq_hdr_aux = -1; // FASTQ text: 0 header kernel in front of the line pass, 2 beside it, -1 / 1 beside line_sum only
     int fastq_one_pass = -1;  // FASTQ text: 1 the one-pass kernels of ppqc_fastq1.hip for every text, 0 never, -1 by the last text's lines
     int fq1_regions = -1;     // ... the number of regions (waves) they split a text into (4096)
+    int fq1_early = -1;       // ... 0: their finalize kernel is launched when the host knows the line count; -1 / 1: straight behind
+                              // the scan, the count read on the device, when the last text's line length says the arrays suffice
     int n50_select = -1;      // local N50: 1 by radix select (three histograms of the lengths) whenever the run left its index at
                               // submit time, 0 by the sort; -1: select behind FASTQ texts, whose lengths are known last
     int fastq_index_aux = -1; // FASTQ text: 0 the extremes kernel in line behind the finalize kernel; -1 / 1 on the auxiliary stream
@@ -143,7 +145,8 @@ uint64_t tables_slab_words(const TableLayout& lay);
 // max_buf[0 .. max_words): words whose largest is the run's largest length (max_buf of the extremes kernels, 1 word; or the
 // sort gate, kGateWords words, when the FASTQ finalize kernels alone have raised it)
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
-                         int max_words, uint64_t* slab, hipStream_t s, int cell_mode, const uint64_t* job_chan_count = nullptr);
+                         int max_words, uint64_t* slab, hipStream_t s, int cell_mode, const uint64_t* job_chan_count = nullptr,
+                         bool one_per_cu = false);
 hipError_t launch_chan_count(ReadArrays ra, uint64_t n, uint32_t n_channels, uint64_t* out, hipStream_t s);
 
 hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s);
@@ -188,10 +191,12 @@ hipError_t launch_n50_gated(const uint32_t* in, const uint32_t* buf_a, const uin
 // hist: sel[d] += sum of the lengths whose bits above `shift + nbits` equal the prefix and whose digit is d.
 // pick: chooses the digit (see include/pypore_qc.h), updates state, zeroes sel; `last` also writes out[0] = N50, out[1] = total.
 hipError_t launch_select_hist(const uint32_t* lens, uint64_t n, int shift, int nbits, const uint64_t* state,
-                              uint64_t* sel, hipStream_t s);
+                              uint64_t* sel, hipStream_t s, const uint64_t* gate = nullptr, int gate_words = 1);
 hipError_t launch_select_pick(uint64_t* sel, const uint64_t* total, uint64_t* state, int shift, int nbits, bool last,
-                              bool first, uint64_t* out, uint64_t* host_out, hipStream_t s);   // total == nullptr: from the first
-                              // round's histogram; host_out (last round, may be null): a pinned word that receives the N50 as well
+                              bool first, uint64_t* out, uint64_t* host_out, hipStream_t s, const uint64_t* gate = nullptr,
+                              int gate_words = 1);   // total == nullptr: from the first round's histogram; host_out (last round, may
+                              // be null): a pinned word that receives the N50 as well; gate: words whose OR bounds every key -- a
+                              // round above its top bit does nothing (both kernels), state[3] tells whether the total is known
 
 // ---- FASTQ text on the GPU (ppqc_fastq_gpu.hip) --------------------------------------------------------------------
 constexpr uint32_t kNlChunk = 8192;   // bytes of text per wave of the line-index kernels (eight 1 KiB spans in registers)
@@ -247,11 +252,16 @@ struct Fq1Scratch {
 uint64_t fq1_chunks(uint64_t n);
 void fq1_shape(uint64_t n, int want_regions, uint32_t* cpr, uint64_t* n_regions);
 hipError_t launch_fq1_scan(const uint8_t* text, uint64_t n, const Fq1Scratch& f, uint32_t cpr, uint64_t n_regions,
-                           const uint64_t* lut_dev, uint64_t* host_out, hipStream_t s);
+                           const uint64_t* lut_dev, uint64_t* host_out, uint64_t ticket, hipStream_t s);   // host_out: five pinned
+                           // words; [0] lines, [1] flags, and last of all [4] = ticket (what the host polls for)
 hipError_t launch_fq1_finalize(const uint8_t* text, uint64_t n, uint64_t n_records, const Fq1Scratch& f, uint32_t cpr,
                                uint64_t n_regions, ReadArrays ra, uint64_t read_base, const uint64_t* lut_dev,
                                const QThr& thr, uint8_t mux, uint64_t* errors, uint32_t n_channels, uint64_t* gate,
                                const Fq1Index& ix, hipStream_t s);   // also writes lens32 and raises the sort gate, like finalize_reads
+hipError_t launch_fq1_finalize_early(const uint8_t* text, uint64_t n, uint64_t max_records, const Fq1Scratch& f, uint32_t cpr, uint64_t n_regions, ReadArrays ra,
+                                     uint64_t read_base, const uint64_t* lut_dev, const QThr& thr, uint8_t mux,
+                                     uint64_t* errors, uint32_t n_channels, uint64_t* gate, const Fq1Index& ix,
+                                     hipStream_t s);   // behind the regions kernel, the record count read on the device
 
 hipError_t launch_synth(uint8_t* bases, uint8_t* quals, uint64_t first, uint64_t n, uint64_t seed, hipStream_t s);
 

@@ -361,8 +361,10 @@ hipError_t launch_n50_gated(const uint32_t* in, const uint32_t* buf_a, const uin
 // ---- N50 by weighted radix select (multi-GPU: only PPQC_N_SEL-word histograms cross xGMI) --------------------------
 __global__ __launch_bounds__(256) void select_hist_kernel(const uint32_t* __restrict__ lens, uint64_t n, int shift,
                                                           int nbits, const uint64_t* __restrict__ state,
-                                                          uint64_t* __restrict__ sel) {
+                                                          uint64_t* __restrict__ sel,
+                                                          const uint64_t* __restrict__ gate, int gate_words) {
     __shared__ unsigned long long h[PPQC_N_SEL];
+    if (gate && shift && (gate_bound(gate, gate_words) >> shift) == 0) return;   // no key has a bit in this round's digit or above
     for (int d = threadIdx.x; d < PPQC_N_SEL; d += blockDim.x) h[d] = 0;
     const uint32_t prefix = (uint32_t)state[0];
     const uint32_t mask_hi = shift + nbits >= 32 ? 0u : ~0u << (shift + nbits);
@@ -396,9 +398,13 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const uint32_t* __rest
 __global__ __launch_bounds__(256) void select_pick_kernel(uint64_t* __restrict__ sel, const uint64_t* __restrict__ total,
                                                           uint64_t* __restrict__ state, int shift, int nbits, int last,
                                                           int first, uint64_t* __restrict__ out,
-                                                          uint64_t* __restrict__ host_out) {
+                                                          uint64_t* __restrict__ host_out,
+                                                          const uint64_t* __restrict__ gate, int gate_words) {
     __shared__ uint64_t part[256];
     __shared__ uint64_t s_T;
+    // gate: the rounds whose digits are zero in every key are skipped on the device (their histogram kernel returned at
+    // once as well); the first round that runs sums its histogram for the total (state[3] says that it has been done)
+    if (gate && shift && (gate_bound(gate, gate_words) >> shift) == 0) return;
     const uint32_t t = threadIdx.x;
     const int per = (1 << nbits) / 256;   // 8 or 4 digits per thread
     const uint64_t prefix = state[0], above = state[1];
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(256) void select_pick_kernel(uint64_t* __restrict__
         for (int i = 255; i >= 0; --i) { const uint64_t x = part[i]; part[i] = run; run += x; }
         uint64_t T;
         if (total) T = total[0];
-        else if (first) { T = run; state[2] = run; }
+        else if (gate ? state[3] == 0 : first != 0) { T = run; state[2] = run; if (gate) state[3] = 1; }
         else T = state[2];
         s_T = T;
     }
@@ -442,18 +448,19 @@ __global__ __launch_bounds__(256) void select_pick_kernel(uint64_t* __restrict__
 }
 
 hipError_t launch_select_hist(const uint32_t* lens, uint64_t n, int shift, int nbits, const uint64_t* state,
-                              uint64_t* sel, hipStream_t s) {
+                              uint64_t* sel, hipStream_t s, const uint64_t* gate, int gate_words) {
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
     if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(select_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, s, lens, n, shift, nbits, state, sel);
+    hipLaunchKernelGGL(select_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, s, lens, n, shift, nbits, state, sel, gate, gate_words);
     return hipGetLastError();
 }
 
 hipError_t launch_select_pick(uint64_t* sel, const uint64_t* total, uint64_t* state, int shift, int nbits, bool last,
-                              bool first, uint64_t* out, uint64_t* host_out, hipStream_t s) {
+                              bool first, uint64_t* out, uint64_t* host_out, hipStream_t s, const uint64_t* gate,
+                              int gate_words) {
     hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, s, sel, total, state, shift, nbits, last ? 1 : 0,
-                       first ? 1 : 0, out, last ? host_out : nullptr);
+                       first ? 1 : 0, out, last ? host_out : nullptr, gate, gate_words);
     return hipGetLastError();
 }
 

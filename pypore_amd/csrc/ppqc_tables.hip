@@ -214,7 +214,7 @@ constexpr uint32_t kRep = 8;
 constexpr uint32_t kHistBins = PPQC_N_LEN_LOG2 + PPQC_N_LEN_LIN + PPQC_N_QHIST + PPQC_N_GCHIST;
 constexpr unsigned kTabThreads = 512, kTabMaxBlocks = 512;
 
-__global__ __launch_bounds__(kTabThreads) void tables_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf,
+__global__ __launch_bounds__(2 * kTabThreads) void tables_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf,
                                                             const uint64_t* max_buf, int max_words, uint32_t nchL,
                                                             int cell_mode, uint64_t* __restrict__ slab) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -538,7 +538,8 @@ hipError_t launch_cmh_unpack(const TableParams& tp, uint64_t* sum_buf, hipStream
 uint64_t tables_slab_words(const TableLayout& lay) { return (uint64_t)kTabMaxBlocks * lay.off_cmh_reads; }
 
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
-                         int max_words, uint64_t* slab, hipStream_t s, int cell_mode, const uint64_t* job_chan_count) {
+                         int max_words, uint64_t* slab, hipStream_t s, int cell_mode, const uint64_t* job_chan_count,
+                         bool one_per_cu) {
     if (n == 0) return hipSuccess;
     const uint32_t nb = tp.lay.n_time_bins;
     // per-channel accumulators in LDS need 16 B per channel; a block stays under 64 KiB, so two fit a CU.  When
@@ -550,8 +551,12 @@ hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint6
     const size_t lds = lds_for(nchL);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     // two blocks of 512 threads per CU (4 waves per SIMD): the kernel is bound by the latency of its eleven loads per read
-    const unsigned blocks = grid_for(n, kTabMaxBlocks);
-    hipLaunchKernelGGL(tables_kernel, dim3(blocks), dim3(kTabThreads), lds, s, ra, n, tp, sum_buf, max_buf, max_words, nchL,
+    // one_per_cu: the same sixteen waves per CU as ONE block of 1024 threads, which leaves LDS for the blocks of the extremes
+    // kernel that runs beside this one behind a FASTQ text (two blocks of this kernel and one of that do not fit a CU)
+    const unsigned threads = one_per_cu ? 2 * kTabThreads : kTabThreads;
+    unsigned blocks = grid_for(n, kTabMaxBlocks);
+    if (one_per_cu) blocks = (blocks + 1) / 2;
+    hipLaunchKernelGGL(tables_kernel, dim3(blocks), dim3(threads), lds, s, ra, n, tp, sum_buf, max_buf, max_words, nchL,
                        cell_mode, slab);
     hipLaunchKernelGGL(tables_reduce_kernel, dim3((unsigned)((tp.lay.off_cmh_reads + 15) / 16)), dim3(256), 0, s, slab, blocks,
                        (uint32_t)tp.lay.off_cmh_reads, sum_buf);

@@ -573,3 +573,44 @@ def test_the_tail_of_a_step_straight_behind_the_texts(qc_mod, c_oracle, tail):
         got = ctx.finalize()
         assert_tables_equal(got, wb, "no channels")
         assert int(got["n50"]) == 0
+
+
+def test_the_finalize_kernel_launched_before_the_line_count_is_known(qc_mod, c_oracle, line_sums_from):
+    """From its second text on a context launches the one-pass finalize kernel straight behind the scan, sized by the last
+    text's line length; the kernel reads the record count on the device and leaves a text alone that the host will not
+    commit as it stands.  Texts like the last one (the kernel runs), a text with far more records than the guess and the
+    arrays' room (the kernel declines, the host grows the arrays and launches again), a text the scan declines (short
+    lines), a text whose lines are no records (an error, nothing committed) -- each against the host packer."""
+    if not line_sums_from.startswith("one_pass"):
+        pytest.skip("the one-pass kernels")
+    long_lens = [5000] * 20
+    mid_lens = [250 + (i % 7) for i in range(3000)]
+    tiny_lens = [30] * 600
+    t_long, t_long2 = _text(301, len(long_lens), lens=long_lens), _text(302, len(long_lens), lens=long_lens, crlf=True)
+    t_mid, t_tiny = _text(303, len(mid_lens), lens=mid_lens), _text(304, len(tiny_lens), lens=tiny_lens)
+    for early in (1, 0):
+        with qc_mod.QCContext(device=0, **CFG) as ctx:
+            ctx.set_tuning("fq1_early", early)
+            plan = [t_long, t_long2, t_mid, t_tiny, t_long]
+            for t in plan:
+                ctx.submit_fastq(t)
+            with pytest.raises(Exception, match="multiple of 4"):
+                ctx.submit_fastq(t_long + b"@stray\n")
+            ctx.submit_fastq(t_long2)
+            plan.append(t_long2)
+            n_early = ctx.path_count("fastq_early")
+            # the second text and the two after the tiny one ran early; the third found too little room, the tiny one
+            # was declined by the scan
+            assert n_early == (3 if early else 0), n_early
+            assert ctx.path_count("fastq_declined") == 1
+            got = ctx.read_stats()
+            tables = ctx.finalize()
+        stats, ch, st = [], [], []
+        for t in plan:
+            p, want, _ = _host_path(qc_mod, c_oracle, t)
+            stats.append(want); ch.append(p["channel"]); st.append(p["start_time"])
+        want = {k: np.concatenate([s[k] for s in stats]) for k in ("length", "gc", "n", "qsum", "mean_q")}
+        want["err"] = [e for s in stats for e in s["err"]]
+        _check(got, want)
+        ch, st = np.concatenate(ch), np.concatenate(st)
+        assert_tables_equal(tables, c_oracle.tables(want, ch, np.ones(len(ch), np.uint8), st, None, CFG), "early=%d" % early)
