@@ -363,8 +363,8 @@ int ppqc_bind_thread(ppqc_ctx* ctx);
  * time, how the GPU FASTQ tokenizer sums its lines), `value` -1 leaves the choice to the library -- the state of every
  * new context -- and other values force one path for this context: "tile_dense" 0|1, "dense_len" bytes, "tile_all" 0|1,
  * "tile_shift" 12..16, "pre" 0|1, "fastq_sums" 0|1|2, "fastq_hdr_aux" 0|1|2, "fastq_one_pass" 0|1, "fq1_regions" n,
- * "sort_beside" 0|1, "n50_select" 0|1 (the local N50 by sort / by radix select), "fastq_index_aux" 0|1 (the extremes of a
- * FASTQ text's reads in line / beside the tables), "fq1_early" 0|1 (the one-pass finalize kernel launched when the host
+ * "sort_beside" 0|1, "n50_select" 0|1 (the local N50 by sort / by radix select), "fastq_extremes" 0|1 (the extremes of a
+ * FASTQ text's reads by a kernel of their own / by the tables kernel of ppqc_finalize), "fq1_early" 0|1 (the one-pass finalize kernel launched when the host
  * knows the line count / straight behind the scan) (pypore_amd/csrc/ppqc_internal.hpp, Tuning).  Results never depend on it (the parity tests run the paths against each
  * other); the library reads no environment variable. */
 int ppqc_set_tuning(ppqc_ctx* ctx, const char* name, int value);

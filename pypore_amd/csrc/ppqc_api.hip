@@ -212,8 +212,8 @@ struct ppqc_ctx {
     bool pre_ok = false;    // every batch since ppqc_reset went that way
     bool index_on_main = false;   // ... the newest of them (a FASTQ text) in line on the main stream, not on the auxiliary one
     bool gate_max_run = true;     // every read of the run so far came from a FASTQ text: the largest gate word is the largest length
-    bool index_pending = false;   // the extremes kernel of the newest text runs on a stream of its own and the main stream has not
-                                  // taken its end (ev_pre) in yet: join_index
+    bool ext_deferred = false;    // the extremes of the run's reads (all from FASTQ texts) have been left to the tables kernel of
+                                  // ppqc_finalize; whoever needs them before that kernel gets them from join_index
     bool pre_run = false;   // ... and the finalize in progress relies on it (set by ppqc_finalize_extremes)
     bool n50_early = false; // ppqc_n50_select_early has left the N50 of the run's reads (no batch since)
     hipEvent_t ev_pre = nullptr;   // behind the newest of those kernels (auxiliary stream)
@@ -265,10 +265,8 @@ static int grow(T** p, uint64_t old_n, uint64_t new_cap, hipStream_t s) {
     return PPQC_OK;
 }
 
-static int join_index(ppqc_ctx* c);
 static int ensure_reads(ppqc_ctx* c, uint64_t need) {
     if (need <= c->cap_reads) return PPQC_OK;
-    CHK(join_index(c));   // the extremes kernel of a FASTQ text may be reading the arrays that move
     uint64_t cap = c->cap_reads ? c->cap_reads * 2 : 1024;
     if (cap < need) cap = need;
     const uint64_t n = c->n_reads;
@@ -343,13 +341,17 @@ static int mark_busy(ppqc_ctx* c) {
     return PPQC_OK;
 }
 
-// The extremes of a FASTQ text's reads may still be running on a stream of their own (fastq_committed): whatever needs
-// them, or is about to touch the arrays they read, on the main stream takes them in here.
+// The extremes of the run's reads were left to the tables kernel of ppqc_finalize (fastq_committed) and someone needs
+// them before that: extremes_kernel<true> over the run's arrays, in line.  (Reads whose extremes are there already are
+// taken in again: maxima and minima do not mind.)
 static int join_index(ppqc_ctx* c) {
-    if (c->index_pending) {
-        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_pre, 0));
-        c->index_pending = false;
+    if (c->ext_deferred && c->n_reads) {
+        BatchView v{nullptr, nullptr, nullptr, c->n_reads, 0, nullptr, kDefaultTileShift, nullptr, nullptr, nullptr};
+        HIPCHK(launch_batch_extremes(v, 0, c->ra, c->tp, c->max_buf, c->min_buf, c->tminmax, c->res_buf + c->res_words + 4,
+                                     c->maxlen_host + 4, nullptr, nullptr, c->stream));
+        HIPCHK(hipEventRecord(c->ev_pre, c->stream));
     }
+    c->ext_deferred = false;
     return PPQC_OK;
 }
 
@@ -576,7 +578,7 @@ int ppqc_destroy(ppqc_ctx* c) {
 int ppqc_reset(ppqc_ctx* c) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
-    CHK(join_index(c));
+    c->ext_deferred = false;
     HIPCHK(hipStreamSynchronize(c->stream));
     // one launch clears the results and the words behind them (input errors, length bound, sort gate); the finalize that
     // follows finds the buffer clean and enqueues no clear of its own
@@ -613,7 +615,6 @@ static int resolve_batch_timings(ppqc_ctx* c, hipEvent_t first_of_last_batch, bo
 // Enqueue the per-read kernels for a batch whose arrays are all in device memory.
 static int run_batch(ppqc_ctx* c, const ppqc_batch* b) {
     const uint64_t R = b->n_reads;
-    CHK(join_index(c));   // a text's extremes kernel and this batch's index kernel share their ticket word
     CHK(ensure_reads(c, c->n_reads + R));
     // 64 KiB tiles (a tile's start-up -- the read search, the first loads -- is 3 % of its time; 12 % at 16 KiB), except
     // for batches too small to give every wave slot of the GPU a few tiles: there the kernel's time is the time of its
@@ -766,19 +767,21 @@ static int fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_reco
         HIPCHK(hipEventRecord(c->ev_reads, c->stream));
         ++c->reads_gen;
         if (pre) {
-            // hours and cells are there (the text's finalize kernel); the extremes over the run's arrays.  When the run
-            // holds reads of texts only, on a stream of its own (the first copy stream: a text's copy into that slot waits
-            // for the kernels of the slot's last text anyway): the gate's largest word is the largest length then, the
-            // one thing the tables kernel needs of the extremes, so that kernel (main stream) and the N50 chain
-            // (auxiliary stream) run beside this one (ppqc_finalize).  Else in line on the main stream.
-            const bool on_aux = c->gate_max_run && c->tn.fastq_index_aux != 0;
-            hipStream_t es = on_aux ? c->copy[0] : c->stream;
-            if (on_aux) HIPCHK(hipStreamWaitEvent(es, c->ev_reads, 0));
-            BatchView v{nullptr, nullptr, nullptr, R, n, nullptr, kDefaultTileShift, nullptr, nullptr, nullptr};
-            HIPCHK(launch_batch_extremes(v, c->n_reads, c->ra, c->tp, c->max_buf, c->min_buf, c->tminmax,
-                                         c->res_buf + c->res_words + 4, c->maxlen_host + 4, nullptr, nullptr, es));
-            HIPCHK(hipEventRecord(c->ev_pre, es));
-            c->index_pending = on_aux;
+            // hours and cells are there (the text's finalize kernel).  The extremes: when the run holds reads of texts
+            // only, the gate's largest word is the largest length, the one thing the tables kernel needs of them -- so
+            // they are left to that kernel (tables_kernel<true>, ppqc_finalize_tables), which reads every read anyway:
+            // an extremes kernel here would stand in the step's tail, the lengths being the last thing a text yields.
+            // Else, or when told so, extremes_kernel<true> over these reads, in line.
+            const bool defer = c->gate_max_run && c->tn.fastq_extremes != 0 && tables_ext_fits(c->tp.lay);
+            if (defer) {
+                c->ext_deferred = true;
+            } else {
+                CHK(join_index(c));   // (earlier texts of the run first)
+                BatchView v{nullptr, nullptr, nullptr, R, n, nullptr, kDefaultTileShift, nullptr, nullptr, nullptr};
+                HIPCHK(launch_batch_extremes(v, c->n_reads, c->ra, c->tp, c->max_buf, c->min_buf, c->tminmax,
+                                             c->res_buf + c->res_words + 4, c->maxlen_host + 4, nullptr, nullptr, c->stream));
+            }
+            HIPCHK(hipEventRecord(c->ev_pre, c->stream));
             c->index_on_main = true;   // whoever takes these results on the auxiliary stream waits for ev_pre (finalize_impl)
             if (cells) c->cells_dirty = true;
             c->last_b = nullptr;   // no per-read kernel whose end the sort chain could start at: behind ev_reads
@@ -1018,7 +1021,6 @@ int ppqc_submit_records(ppqc_ctx* c, const ppqc_records* r) {
     if (!r->length || !r->mean_q || !r->channel || !r->mux || !r->start_time_s)
         return fail(PPQC_E_INVALID, "null record column");
     HIPCHK(hipSetDevice(c->device));
-    CHK(join_index(c));   // the arrays may grow
     CHK(ensure_reads(c, c->n_reads + n));
     // stage the columns in one device buffer (freed after the kernel; this path is I/O bound on the text table)
     const uint64_t o_len = 0, o_q = o_len + n * 4 + 8, o_q8 = (o_q + 7) & ~7ull, o_gc = o_q8 + n * 8,
@@ -1099,7 +1101,6 @@ static int resolve_timings(ppqc_ctx* c) {   // everything, behind a synchronisat
 int ppqc_sync(ppqc_ctx* c) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
-    CHK(join_index(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 2; ++i) c->slot[i].busy = false;
     c->res_busy = false;
@@ -1159,12 +1160,13 @@ int ppqc_read_hours(ppqc_ctx* c, int32_t* out, uint64_t first, uint64_t n) {
     return PPQC_OK;
 }
 
-// defer_index: the caller (ppqc_finalize) takes the end of a FASTQ text's extremes kernel in itself, behind the tables
+// defer_index: the caller (ppqc_finalize) goes on to the tables kernel, which takes the extremes of FASTQ reads along
 static int finalize_extremes_impl(ppqc_ctx* c, bool defer_index) {
     if (!c) return fail(PPQC_E_INVALID, "null context");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    if (!(defer_index && c->res_clean && c->pre_ok && c->gate_max_run)) CHK(join_index(c));
+    if (!(c->res_clean && c->pre_ok)) c->ext_deferred = false;   // the extremes kernel below takes every read of the run
+    else if (!(defer_index && c->gate_max_run)) CHK(join_index(c));
     resolve_finalize_timings(c);   // its events are about to be recorded again
     c->fin_gen = c->reads_gen;
     c->sum_fetched = false;
@@ -1279,12 +1281,14 @@ int ppqc_finalize_tables(ppqc_ctx* c) {
         c->cells_done = true;
         c->cmh_on_host = false;
     }
-    // the largest length: left by an extremes kernel in front of this one, or (that kernel still runs beside, on the
-    // auxiliary stream) the largest word of the gate, which the finalize kernels of the run's FASTQ texts have raised
-    const bool from_gate = c->index_pending && c->pre_run && c->gate_max_run;
-    if (!from_gate) CHK(join_index(c));
-    HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, from_gate ? c->res_buf + c->res_words + 8 : c->max_buf,
-                         from_gate ? kGateWords : 1, c->tab_slab, s, cell_mode, c->cc_ready ? c->cc : nullptr, from_gate));
+    // the largest length: left by an extremes kernel in front of this one, or (the extremes of a run of FASTQ texts are
+    // left to this kernel) the largest word of the gate, which the texts' finalize kernels have raised
+    const bool with_ext = c->ext_deferred && c->pre_run && c->gate_max_run && n != 0;
+    if (!with_ext) CHK(join_index(c));
+    HIPCHK(launch_tables(c->ra, n, c->tp, c->sum_buf, with_ext ? c->res_buf + c->res_words + 8 : c->max_buf,
+                         with_ext ? kGateWords : 1, c->tab_slab, s, cell_mode, c->cc_ready ? c->cc : nullptr,
+                         with_ext ? reinterpret_cast<long long*>(c->max_buf) : nullptr));
+    c->ext_deferred = false;
     c->state = 2;
     if (c->n50_early) {   // the N50 is there already (ppqc_n50_select_early): the finalize ends here
         HIPCHK(hipEventRecord(c->ev_t1, s));
@@ -1365,7 +1369,6 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     // lengths are the last thing known, so that the chain is the tail of the step (4.3 * 10^6 reads: 205 -> 45 us).  The
     // histogram and its state are as ppqc_reset left them (pre_run), and each pick clears the histogram for the next.
     const bool by_select = local && c->pre_run && ss != s && (c->tn.n50_select >= 0 ? c->tn.n50_select != 0 : c->index_on_main);
-    if (ss == s) CHK(join_index(c));
     // pre: the keys come from the batches' index kernels, so the chain does not wait for finalize_reads either: it starts
     // when the per-read kernel ends and runs beside finalize_reads and the tables
     // ... and beside the per-read kernel itself, right behind the index kernels, when that kernel is dense_kernel alone:
@@ -1401,7 +1404,6 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     if (ss == s) HIPCHK(hipEventRecord(c->ev_s1, ss));
     if (ss != s) {
         if (early_out) {   // ppqc_finalize: all but the N50 is final behind the tables kernel; copied beside the sort chain
-            CHK(join_index(c));   // (and behind the extremes of a FASTQ text, which ran beside the tables)
             CHK(copy_results(c, s));
             c->sum_fetched = true;
         }
@@ -1409,7 +1411,6 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
         c->sort_end = c->ev_join;
         HIPCHK(hipEventRecord(c->ev_t1, s));      // end of the main chain; the finalize ends at the later of the two
         HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
-        CHK(join_index(c));
     } else {
         HIPCHK(hipEventRecord(c->ev_t1, s));
     }
@@ -1475,9 +1476,13 @@ static int finalize_impl(ppqc_ctx* c, ppqc_tables* o, bool view) {
     // and copy the region (13.8 MB at 3000 x 4 x 72, the bulk of the result buffer) to the host mirror on a copy stream --
     // all of it beside the per-read kernel, which this call usually finds running.
     if (c->pre_run && c->cells_early && !c->cells_done) {
-        // (a one-pass FASTQ text left them on the main stream: there, and the auxiliary stream stays free for the sort
-        // chain, which can start behind the text's last per-read kernel)
-        hipStream_t us = c->index_on_main ? c->stream : c->aux;
+        // (a FASTQ text left them with its finalize kernel on the main stream: unpack and copy both on the copy stream,
+        // behind that kernel; the main stream goes straight on to the tables, the auxiliary one to the N50)
+        hipStream_t us = c->aux;
+        if (c->index_on_main) {
+            us = c->copy[1];
+            HIPCHK(hipStreamWaitEvent(us, c->ev_reads, 0));
+        }
         CHK(cells_unpack_on(c, us));
         CHK(cells_to_host_on(c, us, c->copy[1]));
     }
@@ -1551,6 +1556,7 @@ int ppqc_stream_wait_index(ppqc_ctx* c, void* stream) {
     if (!(c->pre_ok && c->res_clean && c->cfg.time_mode == 0))
         return fail(PPQC_E_STATE, "the run's batches did not leave their index-only results at submit time");
     HIPCHK(hipSetDevice(c->device));
+    CHK(join_index(c));   // (extremes that were left to the tables kernel: now)
     HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_clean, 0));   // the clear of the result buffer (an empty run)
     if (c->n_reads) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_pre, 0));
     return PPQC_OK;
@@ -1657,7 +1663,7 @@ int ppqc_set_tuning(ppqc_ctx* c, const char* name, int value) {
         {"tile_all", &c->tn.tile_all, -1, 1},           {"tile_shift", &c->tn.tile_shift, -1, kMaxTileShift},
         {"pre", &c->tn.pre, -1, 1},                     {"fastq_sums", &c->tn.fastq_sums, -1, 2},
         {"fastq_hdr_aux", &c->tn.fastq_hdr_aux, -1, 2}, {"sort_beside", &c->tn.sort_beside, -1, 1},
-        {"n50_select", &c->tn.n50_select, -1, 1}, {"fq1_early", &c->tn.fq1_early, -1, 1}, {"fastq_index_aux", &c->tn.fastq_index_aux, -1, 1},
+        {"n50_select", &c->tn.n50_select, -1, 1}, {"fq1_early", &c->tn.fq1_early, -1, 1}, {"fastq_extremes", &c->tn.fastq_extremes, -1, 1},
         {"fastq_one_pass", &c->tn.fastq_one_pass, -1, 1}, {"fq1_regions", &c->tn.fq1_regions, -1, 1 << 20},
     };
     for (auto& k : knobs)

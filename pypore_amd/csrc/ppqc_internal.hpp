@@ -111,8 +111,9 @@ struct Tuning {
                               // the scan, the count read on the device, when the last text's line length says the arrays suffice
     int n50_select = -1;      // local N50: 1 by radix select (three histograms of the lengths) whenever the run left its index at
                               // submit time, 0 by the sort; -1: select behind FASTQ texts, whose lengths are known last
-    int fastq_index_aux = -1; // FASTQ text: 0 the extremes kernel in line behind the finalize kernel; -1 / 1 on the auxiliary stream
-                              // when every read of the run came from a text (the tables take the largest length from the gate)
+    int fastq_extremes = -1;  // FASTQ text: 0 an extremes kernel over its reads in line behind the finalize kernel; -1 / 1: left to
+                              // the tables kernel of ppqc_finalize when every read of the run came from a text (that kernel
+                              // takes the largest length from the gate; whoever needs the extremes earlier gets the kernel then)
 };
 hipError_t launch_tile_kernel(const BatchView& b, const uint64_t* lut_dev, ReadArrays ra, uint64_t read_base,
                               Partial* head, Partial* tail, DenseList& dl, DenseList& slow, const Tuning& tn, hipStream_t s,
@@ -146,7 +147,9 @@ uint64_t tables_slab_words(const TableLayout& lay);
 // sort gate, kGateWords words, when the FASTQ finalize kernels alone have raised it)
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
                          int max_words, uint64_t* slab, hipStream_t s, int cell_mode, const uint64_t* job_chan_count = nullptr,
-                         bool one_per_cu = false);
+                         long long* ext_dst = nullptr);   // ext_dst: the run's extremes as well, merged into the result buffer from
+                                                          // max_buf on (only where tables_ext_fits; max_buf = the sort gate then)
+bool tables_ext_fits(const TableLayout& lay);
 hipError_t launch_chan_count(ReadArrays ra, uint64_t n, uint32_t n_channels, uint64_t* out, hipStream_t s);
 
 hipError_t launch_fill_u64(uint64_t* p, uint64_t n, uint64_t v, hipStream_t s);

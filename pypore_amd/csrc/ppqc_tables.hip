@@ -210,13 +210,22 @@ __global__ __launch_bounds__(256) void chan_count_kernel(const uint32_t* __restr
 // one bin do not all queue on one LDS word.
 // nchL = n_channels when the per-channel accumulators fit in LDS, else 0 (then they go straight to global atomics).
 // cell_mode: 0 the cells are there already (every batch left them at submit time), 1 one packed atomic per read, 2 two.
+// EXT: the extremes of extremes_kernel as well, for a run whose reads came from FASTQ texts (their lengths are the last
+// thing known, so an extremes kernel of their own would stand in the step's tail, in front of this kernel or -- fighting
+// it for LDS -- beside it).  Behind the layout above: u32 chan_max[nchL] | u32 chan_min[nchL] | four u64 run words; the
+// slab grows by [max_buf | min_buf | ~tmin | tmax] in the layout and encoding of the result buffer from max_buf on
+// (minima complemented: everything merges by signed MAX), and tables_reduce_kernel merges them into that buffer.  The one
+// thing this kernel needs of the extremes itself, the largest length, it finds in the sort gate (max_words words that
+// the FASTQ finalize kernels raise by atomicMax).
 constexpr uint32_t kRep = 8;
 constexpr uint32_t kHistBins = PPQC_N_LEN_LOG2 + PPQC_N_LEN_LIN + PPQC_N_QHIST + PPQC_N_GCHIST;
 constexpr unsigned kTabThreads = 512, kTabMaxBlocks = 512;
 
-__global__ __launch_bounds__(2 * kTabThreads) void tables_kernel(ReadArrays ra, uint64_t n, TableParams tp, uint64_t* sum_buf,
-                                                            const uint64_t* max_buf, int max_words, uint32_t nchL,
-                                                            int cell_mode, uint64_t* __restrict__ slab) {
+template <bool EXT>
+__global__ __launch_bounds__(EXT ? 2 * kTabThreads : kTabThreads) void tables_kernel(ReadArrays ra, uint64_t n, TableParams tp,
+                                                                                      uint64_t* sum_buf, const uint64_t* max_buf,
+                                                                                      int max_words, uint32_t nchL, int cell_mode,
+                                                                                      uint64_t* __restrict__ slab, uint32_t slab_stride) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t nb = tp.lay.n_time_bins, nch = tp.lay.n_channels, nmux = tp.lay.n_mux;
     unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(smem);
@@ -229,10 +238,18 @@ __global__ __launch_bounds__(2 * kTabThreads) void tables_kernel(ReadArrays ra, 
     uint32_t* s_hreads = s_gc + PPQC_N_GCHIST * kRep;
     uint32_t* s_creads = s_hreads + nb;
     uint32_t* s_cfail = s_creads + nchL;
+    uint32_t* s_cmax = s_cfail + nchL;                      // EXT only (nchL is even or the words below are not used: see launch_tables)
+    uint32_t* s_cmin = s_cmax + nchL;
+    long long* s_run = reinterpret_cast<long long*>(   // lmax, ~lmin, ~tmin, tmax (at the next 8-byte boundary)
+        smem + ((reinterpret_cast<unsigned char*>(s_cmin + nchL) - smem + 7) & ~(size_t)7));
     const uint32_t n64 = PPQC_N_TOTALS + nb + nchL;
     const uint32_t n32 = kHistBins * kRep + nb + 2 * nchL;
     for (uint32_t k = threadIdx.x; k < n64; k += blockDim.x) s_tot[k] = 0;
     for (uint32_t k = threadIdx.x; k < n32; k += blockDim.x) s_log2[k] = 0;
+    if (EXT) {
+        for (uint32_t k = threadIdx.x; k < nchL; k += blockDim.x) { s_cmax[k] = 0; s_cmin[k] = 0xFFFFFFFFu; }
+        if (threadIdx.x < 4) s_run[threadIdx.x] = threadIdx.x == 0 ? 0 : INT64_MIN;
+    }
     __syncthreads();
 
     unsigned long long* g = reinterpret_cast<unsigned long long*>(sum_buf);
@@ -245,6 +262,8 @@ __global__ __launch_bounds__(2 * kTabThreads) void tables_kernel(ReadArrays ra, 
     const uint32_t rep = threadIdx.x & (kRep - 1);
 
     uint64_t tot[PPQC_TOT_NO_TIME + 1] = {};   // thread-local run totals, added to LDS once at the end
+    uint32_t lmax = 0, lmin = 0xFFFFFFFFu;     // EXT: the thread's extremes over reads with a good channel
+    long long tmin = INT64_MAX, tmax = INT64_MIN;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         tot[PPQC_TOT_N_READS] += 1;
         const uint32_t chn = ra.channel[i];
@@ -262,7 +281,15 @@ __global__ __launch_bounds__(2 * kTabThreads) void tables_kernel(ReadArrays ra, 
         tot[PPQC_TOT_N_N] += ra.nn[i];
         tot[PPQC_TOT_QSUM] += (uint64_t)ra.qsum[i];
         tot[PPQC_TOT_ZERO_LEN] += (L == 0);
-        tot[PPQC_TOT_NO_TIME] += (ra.time[i] == INT64_MIN);
+        const int64_t t = ra.time[i];
+        tot[PPQC_TOT_NO_TIME] += (t == INT64_MIN);
+        if (EXT) {
+            lmax = L > lmax ? L : lmax;
+            if (L > 0 && L < lmin) lmin = L;
+            atomicMax(&s_cmax[c], L);
+            atomicMin(&s_cmin[c], L);
+            if (t != INT64_MIN) { tmin = t < tmin ? t : tmin; tmax = t > tmax ? t : tmax; }
+        }
         atomicAdd(&s_log2[(L == 0 ? 0 : 32 - __clz(L)) * kRep + rep], 1u);
         atomicAdd(&s_lin[(uint32_t)(L / lin_w) * kRep + rep], 1u);
         const uint32_t qb = fl >> 4;   // 1 + the bin of 6+j <= mean_q < 7+j, left by whoever computed mean_q (quality_flags)
@@ -294,9 +321,24 @@ __global__ __launch_bounds__(2 * kTabThreads) void tables_kernel(ReadArrays ra, 
 #pragma unroll
     for (int k = 0; k <= PPQC_TOT_NO_TIME; ++k)
         if (tot[k]) atomicAdd(&s_tot[k], (unsigned long long)tot[k]);
+    if (EXT) {
+        if (lmax) atomicMax(&s_run[0], (long long)lmax);
+        if (lmin != 0xFFFFFFFFu) atomicMax(&s_run[1], ~(long long)lmin);
+        if (tmin != INT64_MAX) { atomicMax(&s_run[2], ~tmin); atomicMax(&s_run[3], tmax); }
+    }
     __syncthreads();
     // the block's tables into its slab, laid out like sum_buf[0, off_cmh_reads)
-    uint64_t* out = slab + (uint64_t)blockIdx.x * tp.lay.off_cmh_reads;
+    uint64_t* out = slab + (uint64_t)blockIdx.x * slab_stride;
+    if (EXT) {   // ... and behind them its extremes, laid out like the result buffer from max_buf on
+        long long* ext = reinterpret_cast<long long*>(out + tp.lay.off_cmh_reads);
+        const uint32_t nch1 = nch + 1;
+        if (threadIdx.x == 0) { ext[0] = s_run[0]; ext[nch1] = s_run[1]; ext[2 * nch1] = s_run[2]; ext[2 * nch1 + 1] = s_run[3]; }
+        for (uint32_t k = threadIdx.x; k < nch; k += blockDim.x) {
+            const uint32_t mn = s_cmin[k];
+            ext[1 + k] = mn != 0xFFFFFFFFu ? (long long)s_cmax[k] : INT64_MIN;   // unseen channel: nothing to merge
+            ext[nch1 + 1 + k] = mn != 0xFFFFFFFFu ? ~(long long)mn : INT64_MIN;
+        }
+    }
     for (uint32_t k = threadIdx.x; k < PPQC_N_TOTALS; k += blockDim.x) out[tp.lay.off_totals + k] = s_tot[k];
     for (uint32_t k = threadIdx.x; k < kHistBins; k += blockDim.x) {   // the four histograms lie back to back in both layouts
         uint32_t v = 0;
@@ -316,30 +358,51 @@ __global__ __launch_bounds__(2 * kTabThreads) void tables_kernel(ReadArrays ra, 
 }
 
 // sum_buf[k] += sum over the blocks' slabs, k < n_small: 16 words per block of 256 threads, sixteen threads per word with
-// four loads in flight each (the kernel is nothing but the latency of its loads)
+// four loads in flight each (the kernel is nothing but the latency of its loads).  Words n_small .. n_small + n_ext of a
+// slab (tables_kernel<true>): merged by signed MAX into ext_dst[k - n_small] -- the result buffer from max_buf on --
+// except word tmin_at, which holds a complemented minimum for a word that is kept plain.
 __global__ __launch_bounds__(256) void tables_reduce_kernel(const uint64_t* __restrict__ slab, uint32_t n_slabs,
-                                                            uint32_t n_small, uint64_t* sum_buf) {
+                                                            uint32_t stride, uint32_t n_small, uint64_t* sum_buf,
+                                                            uint32_t n_ext, long long* ext_dst, uint32_t tmin_at) {
     __shared__ uint64_t part[16][16];
     const uint32_t w = threadIdx.x & 15, q = threadIdx.x >> 4;
     const uint32_t k = blockIdx.x * 16 + w;
+    const bool is_ext = k >= n_small;   // block-uniform when n_small is a multiple of 16; correct either way
     uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
     if (k < n_small) {
         uint32_t b = q;
         for (; b + 48 < n_slabs; b += 64) {
-            v0 += slab[(uint64_t)b * n_small + k];
-            v1 += slab[(uint64_t)(b + 16) * n_small + k];
-            v2 += slab[(uint64_t)(b + 32) * n_small + k];
-            v3 += slab[(uint64_t)(b + 48) * n_small + k];
+            v0 += slab[(uint64_t)b * stride + k];
+            v1 += slab[(uint64_t)(b + 16) * stride + k];
+            v2 += slab[(uint64_t)(b + 32) * stride + k];
+            v3 += slab[(uint64_t)(b + 48) * stride + k];
         }
-        for (; b < n_slabs; b += 16) v0 += slab[(uint64_t)b * n_small + k];
+        for (; b < n_slabs; b += 16) v0 += slab[(uint64_t)b * stride + k];
+        v0 += v1 + v2 + v3;
+    } else if (k < n_small + n_ext) {
+        long long m = INT64_MIN;
+        for (uint32_t b = q; b < n_slabs; b += 16) {
+            const long long x = (long long)slab[(uint64_t)b * stride + k];
+            m = x > m ? x : m;
+        }
+        v0 = (uint64_t)m;
     }
-    part[q][w] = v0 + v1 + v2 + v3;
+    part[q][w] = v0;
     __syncthreads();
     if (q == 0 && k < n_small) {
         uint64_t t = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) t += part[j][w];
         sum_buf[k] += t;
+    } else if (q == 0 && is_ext && k < n_small + n_ext) {
+        long long m = INT64_MIN;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) m = (long long)part[j][w] > m ? (long long)part[j][w] : m;
+        const uint32_t e = k - n_small;
+        if (m != INT64_MIN) {
+            if (e == tmin_at) { if (~m < ext_dst[e]) ext_dst[e] = ~m; }
+            else if (m > ext_dst[e]) ext_dst[e] = m;
+        }
     }
 }
 
@@ -535,31 +598,57 @@ hipError_t launch_cmh_unpack(const TableParams& tp, uint64_t* sum_buf, hipStream
     return hipGetLastError();
 }
 
-uint64_t tables_slab_words(const TableLayout& lay) { return (uint64_t)kTabMaxBlocks * lay.off_cmh_reads; }
+// a slab holds a block's sums and, behind them, its extremes (tables_kernel<true>)
+static inline uint32_t tables_ext_words(const TableLayout& lay) { return 2 * (lay.n_channels + 1) + 2; }
+uint64_t tables_slab_words(const TableLayout& lay) { return (uint64_t)kTabMaxBlocks * (lay.off_cmh_reads + tables_ext_words(lay)); }
 
+static inline uint64_t tables_lds(const TableLayout& lay, uint32_t k, bool ext) {
+    const uint64_t nb = lay.n_time_bins;
+    return 8ull * (PPQC_N_TOTALS + nb + k) + 4ull * (kHistBins * kRep + nb + 2ull * k) + (ext ? 8ull * k + 8 + 32 : 0);
+}
+// tables_kernel<true> keeps six accumulators per channel in LDS: one block of 1024 threads per CU, up to 128 KiB
+bool tables_ext_fits(const TableLayout& lay) { return lay.n_channels <= 3584 && tables_lds(lay, lay.n_channels, true) <= 128 * 1024; }
+
+// ext_dst != nullptr: the extremes as well (tables_kernel<true>), merged into ext_dst = the result buffer from max_buf on;
+// max_buf[0 .. max_words) are then the words of the sort gate.  The caller has asked tables_ext_fits.
 hipError_t launch_tables(ReadArrays ra, uint64_t n, const TableParams& tp, uint64_t* sum_buf, const uint64_t* max_buf,
                          int max_words, uint64_t* slab, hipStream_t s, int cell_mode, const uint64_t* job_chan_count,
-                         bool one_per_cu) {
+                         long long* ext_dst) {
     if (n == 0) return hipSuccess;
-    const uint32_t nb = tp.lay.n_time_bins;
+    const bool ext = ext_dst != nullptr;
     // per-channel accumulators in LDS need 16 B per channel; a block stays under 64 KiB, so two fit a CU.  When
     // channels and time bins together do not fit (3000 channels x 2048 bins), the per-channel accumulators go straight
     // to global atomics (nchL = 0); the rest fits for every n_time_bins ppqc_create accepts (4096: 55 KiB).
-    auto lds_for = [nb](uint32_t k) { return 8ull * (PPQC_N_TOTALS + nb + k) + 4ull * (kHistBins * kRep + nb + 2ull * k); };
     uint32_t nchL = tp.lay.n_channels <= 3584 ? tp.lay.n_channels : 0;
-    if (lds_for(nchL) > 64 * 1024) nchL = 0;
-    const size_t lds = lds_for(nchL);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
-    // two blocks of 512 threads per CU (4 waves per SIMD): the kernel is bound by the latency of its eleven loads per read
-    // one_per_cu: the same sixteen waves per CU as ONE block of 1024 threads, which leaves LDS for the blocks of the extremes
-    // kernel that runs beside this one behind a FASTQ text (two blocks of this kernel and one of that do not fit a CU)
-    const unsigned threads = one_per_cu ? 2 * kTabThreads : kTabThreads;
-    unsigned blocks = grid_for(n, kTabMaxBlocks);
-    if (one_per_cu) blocks = (blocks + 1) / 2;
-    hipLaunchKernelGGL(tables_kernel, dim3(blocks), dim3(threads), lds, s, ra, n, tp, sum_buf, max_buf, max_words, nchL,
-                       cell_mode, slab);
-    hipLaunchKernelGGL(tables_reduce_kernel, dim3((unsigned)((tp.lay.off_cmh_reads + 15) / 16)), dim3(256), 0, s, slab, blocks,
-                       (uint32_t)tp.lay.off_cmh_reads, sum_buf);
+    if (ext) {
+        if (!tables_ext_fits(tp.lay)) return hipErrorInvalidValue;
+    } else if (tables_lds(tp.lay, nchL, false) > 64 * 1024) {
+        nchL = 0;
+    }
+    const size_t lds = tables_lds(tp.lay, nchL, ext);
+    if (!ext && lds > 64 * 1024) return hipErrorInvalidValue;
+    const uint32_t n_small = (uint32_t)tp.lay.off_cmh_reads, n_ext = ext ? tables_ext_words(tp.lay) : 0u;
+    const uint32_t stride = n_small + n_ext;
+    unsigned blocks;
+    if (ext) {
+        // one block of 1024 threads per CU: the same four waves per SIMD, one set of tables per CU
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tables_kernel<true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        const uint64_t b = (n + 2 * kTabThreads - 1) / (2 * kTabThreads);
+        blocks = (unsigned)(b > kTabMaxBlocks / 2 ? kTabMaxBlocks / 2 : b);
+        hipLaunchKernelGGL(tables_kernel<true>, dim3(blocks), dim3(2 * kTabThreads), lds, s, ra, n, tp, sum_buf, max_buf,
+                           max_words, nchL, cell_mode, slab, stride);
+    } else {
+        // two blocks of 512 threads per CU (4 waves per SIMD): the kernel is bound by the latency of its eleven loads per read
+        blocks = grid_for(n, kTabMaxBlocks);
+        hipLaunchKernelGGL(tables_kernel<false>, dim3(blocks), dim3(kTabThreads), lds, s, ra, n, tp, sum_buf, max_buf,
+                           max_words, nchL, cell_mode, slab, stride);
+    }
+    hipLaunchKernelGGL(tables_reduce_kernel, dim3((unsigned)((stride + 15) / 16)), dim3(256), 0, s, slab, blocks, stride,
+                       n_small, sum_buf, n_ext, ext_dst, 2 * (tp.lay.n_channels + 1));
     if (cell_mode == 1) {
         const hipError_t e = launch_cmh_unpack(tp, sum_buf, s);
         if (e != hipSuccess) return e;

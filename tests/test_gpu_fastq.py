@@ -518,7 +518,7 @@ def test_a_text_of_short_reads_at_size(qc_mod, c_oracle, line_sums_from):
         assert_tables_equal(ctx.finalize(), wt)
 
 
-TAILS = [dict(), dict(fastq_index_aux=0), dict(n50_select=0), dict(fastq_index_aux=0, n50_select=0), dict(n50_select=1)]
+TAILS = [dict(), dict(fastq_extremes=0), dict(n50_select=0), dict(fastq_extremes=0, n50_select=0), dict(n50_select=1)]
 
 
 @pytest.mark.parametrize("tail", TAILS, ids=lambda t: ",".join("%s=%d" % kv for kv in t.items()) or "default")
