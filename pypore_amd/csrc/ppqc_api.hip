@@ -1364,11 +1364,14 @@ static int finalize_n50_impl(ppqc_ctx* c, const uint32_t* dlens, uint64_t n, boo
     // (not behind a one-pass FASTQ text: its extremes end just in front of this call, the host would wait for them with
     // nothing enqueued behind; the chain starts behind the text's last per-read kernel, gated on the device)
     const bool pre = local && c->pre_run && ss != s && !c->index_on_main;
-    // By radix select instead (three histograms of the lengths and three one-block picks: six short launches that read the
-    // lengths three times, where the sort reads and writes them once per byte of the largest): behind a FASTQ text, whose
-    // lengths are the last thing known, so that the chain is the tail of the step (4.3 * 10^6 reads: 205 -> 45 us).  The
-    // histogram and its state are as ppqc_reset left them (pre_run), and each pick clears the histogram for the next.
-    const bool by_select = local && c->pre_run && ss != s && (c->tn.n50_select >= 0 ? c->tn.n50_select != 0 : c->index_on_main);
+    // By radix select instead of the sort (three histograms of the lengths and three one-block picks: six short launches
+    // that read the lengths at most three times -- a round above the gate's top bit returns at once -- where the sort
+    // reads and writes them once per byte of the largest), whenever the histogram and its state are as ppqc_reset left
+    // them (pre_run; each pick clears the histogram for the next).  Behind a FASTQ text, whose lengths are the last thing
+    // known, the chain is the tail of the step (2 * 10^6 reads: 205 -> 45 us); beside the per-read kernel of a CSR batch
+    // it takes less from that kernel (4 * 10^6 reads of 500 bases: 1.227 -> 1.183 ms for the step), and the host does not
+    // wait for the largest length.  Tuning::n50_select = 0: the sort.
+    const bool by_select = local && c->pre_run && ss != s && c->tn.n50_select != 0;
     // pre: the keys come from the batches' index kernels, so the chain does not wait for finalize_reads either: it starts
     // when the per-read kernel ends and runs beside finalize_reads and the tables
     // ... and beside the per-read kernel itself, right behind the index kernels, when that kernel is dense_kernel alone:

@@ -109,8 +109,8 @@ struct Tuning {
     int fq1_regions = -1;     // ... the number of regions (waves) they split a text into (4096)
     int fq1_early = -1;       // ... 0: their finalize kernel is launched when the host knows the line count; -1 / 1: straight behind
                               // the scan, the count read on the device, when the last text's line length says the arrays suffice
-    int n50_select = -1;      // local N50: 1 by radix select (three histograms of the lengths) whenever the run left its index at
-                              // submit time, 0 by the sort; -1: select behind FASTQ texts, whose lengths are known last
+    int n50_select = -1;      // local N50: -1 / 1 by radix select (three histograms of the lengths) whenever the run left its index at
+                              // submit time, 0 by the sort
     int fastq_extremes = -1;  // FASTQ text: 0 an extremes kernel over its reads in line behind the finalize kernel; -1 / 1: left to
                               // the tables kernel of ppqc_finalize when every read of the run came from a text (that kernel
                               // takes the largest length from the gate; whoever needs the extremes earlier gets the kernel then)
