@@ -774,14 +774,16 @@ static int fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_reco
             // Else, or when told so, extremes_kernel<true> over these reads, in line.
             const bool defer = c->gate_max_run && c->tn.fastq_extremes != 0 && tables_ext_fits(c->tp.lay);
             if (defer) {
-                c->ext_deferred = true;
+                c->ext_deferred = true;   // (ev_pre is recorded behind the extremes kernel, should one be wanted: join_index;
+                                          // until then ev_reads stands behind everything these reads have left -- each
+                                          // record on the stream costs the kernel behind it some 6 us)
             } else {
                 CHK(join_index(c));   // (earlier texts of the run first)
                 BatchView v{nullptr, nullptr, nullptr, R, n, nullptr, kDefaultTileShift, nullptr, nullptr, nullptr};
                 HIPCHK(launch_batch_extremes(v, c->n_reads, c->ra, c->tp, c->max_buf, c->min_buf, c->tminmax,
                                              c->res_buf + c->res_words + 4, c->maxlen_host + 4, nullptr, nullptr, c->stream));
+                HIPCHK(hipEventRecord(c->ev_pre, c->stream));
             }
-            HIPCHK(hipEventRecord(c->ev_pre, c->stream));
             c->index_on_main = true;   // whoever takes these results on the auxiliary stream waits for ev_pre (finalize_impl)
             if (cells) c->cells_dirty = true;
             c->last_b = nullptr;   // no per-read kernel whose end the sort chain could start at: behind ev_reads
@@ -848,7 +850,6 @@ static int run_fastq_one_pass(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint
     // No event behind the regions kernel: an event record between two kernels of a stream costs the second one some 20 us
     // here, and the finalize kernel may follow at once (below).  The host polls the ticket word instead.
     const uint64_t ticket = ++c->fq1_ticket;
-    HIPCHK(launch_fq1_scan(text, n, c->fq1, cpr, n_regions, c->lut_dev, h + 1, ticket, s));
     // The index-only results of these reads with the finalize kernel, as a CSR batch leaves them when it is submitted
     // (run_batch): the finalize then needs no extremes kernel and the tables no cell atomics.
     const bool pre = c->pre_ok && c->res_clean && c->cfg.time_mode == 0 && c->tn.pre != 0;
@@ -857,6 +858,8 @@ static int run_fastq_one_pass(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint
     // hold a few more than that, the kernel takes the count from the regions kernel's words and goes ahead unless it
     // finds the text declined, its lines no multiple of four, or more records than `room` -- the very tests the host
     // makes below on the same words, so both know whether it ran.
+    // (That kernel then hands the line count to the host as well, first thing: a regions kernel that has stored to host
+    // memory keeps the kernel behind it waiting for some 12 us.)
     uint64_t room = 0;
     bool early = false, early_cells = false;
     if (c->tn.fq1_early != 0 && c->fq_line_hint > 0) {
@@ -871,12 +874,14 @@ static int run_fastq_one_pass(ppqc_ctx* c, const uint8_t* text, uint64_t n, uint
         if (room >= guess + guess / 16) {
             room = guess + guess / 16;   // a thread per record it may hold: 6 % of them idle when the guess is right
             Fq1Index ix{pre ? 1 : 0, c->tp, early_cells ? c->sum_buf + c->tp.lay.off_cmh_bases : nullptr};
+            HIPCHK(launch_fq1_scan(text, n, c->fq1, cpr, n_regions, c->lut_dev, nullptr, 0, s));
             HIPCHK(launch_fq1_finalize_early(text, n, room, c->fq1, cpr, n_regions, c->ra, c->n_reads, c->lut_dev,
                                              c->qthr, mux, c->res_buf + c->res_words, c->cfg.n_channels,
-                                             c->res_buf + c->res_words + 8, ix, s));
+                                             c->res_buf + c->res_words + 8, ix, h + 1, ticket, s));
             early = true;
         }
     }
+    if (!early) HIPCHK(launch_fq1_scan(text, n, c->fq1, cpr, n_regions, c->lut_dev, h + 1, ticket, s));
     CHK(wait_pinned_word(h + 5, ticket, s));
     const uint64_t n_lines = h[1];
     c->fq_line_hint = n_lines ? (int64_t)(n / n_lines) : -1;

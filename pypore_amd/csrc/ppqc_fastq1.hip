@@ -614,9 +614,17 @@ __global__ __launch_bounds__(256) void fq1_finalize_kernel(const uint8_t* __rest
                                                            QThr thr, uint8_t mux, uint64_t* __restrict__ errors,
                                                            uint32_t n_channels, uint64_t* __restrict__ gate,
                                                            float reg_per_line, Fq1Index ix,
-                                                           const uint64_t* __restrict__ head, uint64_t max_records) {
+                                                           const uint64_t* __restrict__ head, uint64_t max_records,
+                                                           uint64_t* __restrict__ host_out, uint64_t ticket) {
     __shared__ unsigned int s_mis, s_bad, s_max;
     if (head != nullptr) {
+        if (host_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+            // the pinned words the host polls (launch_fq1_scan): from here, so that the regions kernel in front ends
+            // without stores to host memory behind it and this kernel starts at once
+            host_out[0] = head[0]; host_out[1] = head[1];
+            __threadfence_system();
+            __hip_atomic_store(&host_out[4], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         // launched before the host knew the text's lines (launch_fq1_finalize_early): the count comes from the regions
         // kernel's words, and a text the host will not commit as it stands (declined by the scan, lines that are no
         // records, more records than the arrays hold) is left alone -- the host sees the same words and does the rest
@@ -768,7 +776,8 @@ hipError_t launch_fq1_finalize(const uint8_t* text, uint64_t n, uint64_t n_recor
     hipLaunchKernelGGL(fq1_finalize_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, s, text, n,
                        n_records, f.points, f.regions, n_regions, cpr * kFq1LinesPerChunk, (uint64_t)cpr * kFq1Chunk, ra,
                        read_base, lut_dev, thr, mux, errors, n_channels, gate,
-                       (float)((double)n_regions / (4.0 * (double)n_records)), ix, (const uint64_t*)nullptr, (uint64_t)0);
+                       (float)((double)n_regions / (4.0 * (double)n_records)), ix, (const uint64_t*)nullptr, (uint64_t)0,
+                       (uint64_t*)nullptr, (uint64_t)0);
     return hipGetLastError();
 }
 
@@ -778,11 +787,12 @@ hipError_t launch_fq1_finalize(const uint8_t* text, uint64_t n, uint64_t n_recor
 hipError_t launch_fq1_finalize_early(const uint8_t* text, uint64_t n, uint64_t max_records, const Fq1Scratch& f, uint32_t cpr, uint64_t n_regions, ReadArrays ra,
                                      uint64_t read_base, const uint64_t* lut_dev, const QThr& thr, uint8_t mux,
                                      uint64_t* errors, uint32_t n_channels, uint64_t* gate, const Fq1Index& ix,
-                                     hipStream_t s) {
-    if (max_records == 0) return hipSuccess;
+                                     uint64_t* host_out, uint64_t ticket, hipStream_t s) {
+    if (max_records == 0) max_records = 1;   // (the kernel must run: it hands the line count to the host)
     hipLaunchKernelGGL(fq1_finalize_kernel, dim3((unsigned)((max_records + 255) / 256)), dim3(256), 0, s, text, n,
                        (uint64_t)0, f.points, f.regions, n_regions, cpr * kFq1LinesPerChunk, (uint64_t)cpr * kFq1Chunk, ra,
-                       read_base, lut_dev, thr, mux, errors, n_channels, gate, 0.0f, ix, (const uint64_t*)f.head, max_records);
+                       read_base, lut_dev, thr, mux, errors, n_channels, gate, 0.0f, ix, (const uint64_t*)f.head, max_records,
+                       host_out, ticket);
     return hipGetLastError();
 }
 

@@ -264,7 +264,8 @@ hipError_t launch_fq1_finalize(const uint8_t* text, uint64_t n, uint64_t n_recor
 hipError_t launch_fq1_finalize_early(const uint8_t* text, uint64_t n, uint64_t max_records, const Fq1Scratch& f, uint32_t cpr, uint64_t n_regions, ReadArrays ra,
                                      uint64_t read_base, const uint64_t* lut_dev, const QThr& thr, uint8_t mux,
                                      uint64_t* errors, uint32_t n_channels, uint64_t* gate, const Fq1Index& ix,
-                                     hipStream_t s);   // behind the regions kernel, the record count read on the device
+                                     uint64_t* host_out, uint64_t ticket, hipStream_t s);   // behind the regions kernel, the record
+                                     // count read on the device; host_out / ticket: as launch_fq1_scan (which then gets none)
 
 hipError_t launch_synth(uint8_t* bases, uint8_t* quals, uint64_t first, uint64_t n, uint64_t seed, hipStream_t s);
 
