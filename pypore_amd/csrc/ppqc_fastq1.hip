@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
     //   w: byte sum (16 bits) | lane * 16 + vector << 16 | bits 0 .. 5 of the newlines << 26
     __shared__ uint4 br[4][kFq1Cap];
     __shared__ uint4 bx[4][kFq1Keep];   // the first kFq1Keep of those vectors themselves (the others are read again)
+    __shared__ uint2 bn[4][kFq1Keep];   // ... with the word in front of each and the word behind it, where the lane holds them
     lut2[threadIdx.x] = lut2_entry(threadIdx.x, lut_g[threadIdx.x]);
     __syncthreads();
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
         uint64_t r_err = 0;                       // the lane's running sums over its strip, in front of the vector at hand
         uint32_t r_gno = 0, r_qb = 0, r_nl = 0;   // (r_gno: its last vector kept apart, so that no field of it passes 240)
         uint32_t last_gno = 0;
+        uint32_t tailw = 0;                       // last word of the strip's first half
         uint32_t ne = 0;                          // newline vectors of the chunk so far (wave-uniform)
         for (int h = 0; h < 2; ++h) {
             const uint64_t sb = cb + (uint64_t)lane * 256 + (uint64_t)h * 128;
@@ -188,7 +190,12 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
                         if (at < (uint32_t)kFq1Cap) {
                             br[wib][at] = make_uint4((uint32_t)r_err, (uint32_t)(r_err >> 32) | ((r_nl >> 6) << 28), r_gno,
                                                      r_qb | ((uint32_t)(lane * 16 + h * 8 + j) << 16) | ((r_nl & 63u) << 26));
-                            if (at < (uint32_t)kFq1Keep) bx[wib][at] = x;
+                            if (at < (uint32_t)kFq1Keep) {
+                                bx[wib][at] = x;
+                                // the neighbours in the lane's registers (the strip's two outer ends and the first half's
+                                // last vector have none here: the compact pass reads the text where it needs them)
+                                bn[wib][at] = make_uint2(j ? vv[j ? j - 1 : 0].w : tailw, vv[j < kFq1Vecs - 1 ? j + 1 : j].x);
+                            }
                         } else {
                             over = true;
                         }
@@ -198,6 +205,7 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
                 }
                 r_err += s.err; last_gno = s.gno; r_qb = f1_bytesum(x, r_qb);
             }
+            tailw = vv[kFq1Vecs - 1].w;
         }
         if (ne > (uint32_t)kFq1Cap) ne = kFq1Cap;   // (the region is flagged: its points will not be used)
         // join the lanes: six inclusive scans of the lane totals (every partial sum fits 32 bits: 256 bytes per lane)
@@ -215,12 +223,15 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
             const uint32_t vi = (rr.w >> 16) & 0x3FFu;
             const uint64_t gpos0 = cb + (uint64_t)vi * 16;
             uint32_t pre = 0x78787878u, post = 0;   // the text around the vector ('x': no white space in front of the text)
+            const bool kept = eb + (uint32_t)lane < (uint32_t)kFq1Keep;
             if (live) {
-                if (eb + (uint32_t)lane < (uint32_t)kFq1Keep) x = bx[wib][eb + lane];
-                else x = f1_load(text, gpos0, n, ends_nl);   // a cache hit, mostly: the wave has just read it
-                if (gpos0 >= 4) pre = *reinterpret_cast<const uint32_t*>(text + gpos0 - 4);
-                if (gpos0 + 20 <= n) post = *reinterpret_cast<const uint32_t*>(text + gpos0 + 16);
-                else if (gpos0 + 16 < n) post = (uint32_t)text[gpos0 + 16];   // its first byte is all that is looked at
+                if (kept) {
+                    x = bx[wib][eb + lane];
+                    const uint2 nb = bn[wib][eb + lane];
+                    pre = nb.x; post = nb.y;
+                } else {
+                    x = f1_load(text, gpos0, n, ends_nl);
+                }
             }
             const int src = (int)(vi >> 4);   // the lane that owns the vector
             const uint32_t e1 = (uint32_t)__shfl((int)(i1 - o1), src), e2 = (uint32_t)__shfl((int)(i2 - o2), src);
@@ -235,6 +246,16 @@ __global__ __launch_bounds__(256) void fq1_scan_kernel(const uint8_t* __restrict
             const uint32_t rel0 = (uint32_t)(c - c0) * kFq1Chunk + vi * 16;
             uint32_t bits = nl_nibble(x.x) | (nl_nibble(x.y) << 4) | (nl_nibble(x.z) << 8) | (nl_nibble(x.w) << 12);
             if (!live) bits = 0;
+            // the neighbouring words from the text where LDS does not hold them and a newline stands where they matter (the
+            // vector's first two bytes, its last): a few per cent of the vectors -- reading them for every vector made
+            // the kernel fetch a fifth more than the text, the lines having left the L2 by then
+            if ((bits & 3u) != 0 && !(kept && (vi & 15u) != 0) && gpos0 >= 4)
+                pre = *reinterpret_cast<const uint32_t*>(text + gpos0 - 4);
+            if ((bits >> 15) != 0 && !(kept && (vi & 7u) != 7u)) {
+                post = 0;
+                if (gpos0 + 20 <= n) post = *reinterpret_cast<const uint32_t*>(text + gpos0 + 16);
+                else if (gpos0 + 16 < n) post = (uint32_t)text[gpos0 + 16];   // its first byte is all that is looked at
+            }
             // sums of the vector's bytes in front of the newline at hand: from a masked lookup of the whole vector for
             // its first newline, for a further one up to three bytes on ("\n+\n") by adding the bytes between
             int pb = -1;
