@@ -2,7 +2,7 @@
 """bench.py -- Gbases/s of the per-read QC statistics path (BASELINE.json metric) on N MI355X of one node.
 
 A step = one whole pass of the hot path over one resident batch: reset, per-read segmented reduction over the CSR
-batch, per-read finalisation, extremes, run-level tables, radix sort + N50 and, for N > 1, the RCCL merges
+batch, per-read finalisation, extremes, run-level tables, the exact N50 (radix select) and, for N > 1, the RCCL merges
 (all-reduce MAX/MIN of the extremes, all-reduce SUM of the fused table buffer, all-gather of the lengths).
 Inputs are synthetic (BASELINE.md config 2 shape: 1 M reads per GPU, log-normal lengths with N50 ~ 20 kb, about
 10 Gbases + 10 Gquals per GPU) and are generated in HBM before the timed region.  Weak scaling: every rank holds its
@@ -163,7 +163,7 @@ def workload_text(a, R, n_bytes):
         shape = "99.95 % reads of 200 b + 100 reads of 2 Mb scattered through the batch"
     else:
         shape = "lognormal(mu=%.4f, sigma=%.4f) clipped [1, 2e6]" % (a.mu, a.sigma)
-    return "%s: %d reads/GPU, %s, %.2f Gbases + quals per GPU, %d channels, %d hourly bins, tables + radix-sort N50 " \
+    return "%s: %d reads/GPU, %s, %.2f Gbases + quals per GPU, %d channels, %d hourly bins, tables + exact N50 " \
            "included" % (a.workload, R, shape, n_bytes / 1e9, a.channels, a.time_bins)
 
 

@@ -135,6 +135,14 @@ struct EvPair {
 //   cells_done    ppqc_cells_early(0), ppqc_finalize          any new batch, ppqc_reset, a clear             finalize_tables (leaves the cells alone)
 //   cmh_on_host   ppqc_cells_early(1), ppqc_finalize          as cells_done                                  the result copies (small tables only)
 //   cc_ready      ppqc_compat_dist_count                      finalize_extremes                             finalize_tables (job-wide channel counts)
+//   index_on_main a FASTQ text that left its index-only      a CSR batch that left its own (auxiliary       ppqc_finalize (cells: unpack and copy on the
+//                 results (its finalize kernel, main stream)  stream), ppqc_reset                            copy stream), finalize_n50 (no host wait)
+//   gate_max_run  ppqc_create / ppqc_reset                    a CSR batch, records, a text without index     fastq_committed, finalize_extremes / _tables
+//                 (every read so far came from a FASTQ text:   results (they raise the gate by OR)           (the gate's largest word is the largest
+//                 the gate's words hold maxima)                                                              length: tables_kernel<true>)
+//   ext_deferred  a FASTQ text whose extremes were left to    join_index (the extremes kernel, when someone  finalize_tables (tables_kernel<true>),
+//                 the tables kernel (gate_max_run)            asks before the tables), finalize_tables,      ppqc_finalize_extremes, _stream_wait_index
+//                                                              ppqc_reset, a finalize that takes every read
 //   fin_pending / end_split / fin_start / sort_start / sort_end: timing bookkeeping only (resolve_finalize_timings).
 //
 // tests/test_gpu_sequences.py drives random interleavings of every entry point against the oracle; any flag read before it

@@ -236,7 +236,7 @@ class QCContext:
         return out
 
     def finalize(self, copy=True):
-        """Single-GPU run-level tables (extremes -> tables -> radix sort + N50 -> fetch).  ``copy=False`` returns views
+        """Single-GPU run-level tables (extremes -> tables -> N50 by radix select, or sort -> fetch).  ``copy=False`` returns views
         of the context's pinned result buffer instead of fresh arrays: valid until the next finalize / fetch of this
         context (for callers that consume the tables at once)."""
         if not copy:
