@@ -792,7 +792,7 @@ static int fastq_committed(ppqc_ctx* c, uint64_t R, uint64_t n, uint64_t* n_reco
                                              c->res_buf + c->res_words + 4, c->maxlen_host + 4, nullptr, nullptr, c->stream));
                 HIPCHK(hipEventRecord(c->ev_pre, c->stream));
             }
-            c->index_on_main = true;   // whoever takes these results on the auxiliary stream waits for ev_pre (finalize_impl)
+            c->index_on_main = true;   // whoever takes these results on another stream waits for ev_reads (finalize_impl)
             if (cells) c->cells_dirty = true;
             c->last_b = nullptr;   // no per-read kernel whose end the sort chain could start at: behind ev_reads
             c->last_dense_alone = false;
@@ -818,6 +818,7 @@ static int wait_pinned_word(const uint64_t* w, uint64_t want, hipStream_t s) {
     const volatile uint64_t* vw = w;
     for (uint64_t spin = 1;; ++spin) {
         if (*vw == want) break;
+        __builtin_ia32_pause();
         if ((spin & 0xFFFF) == 0) {
             const hipError_t e = hipStreamQuery(s);
             if (e == hipErrorNotReady) continue;

@@ -467,8 +467,11 @@ __device__ __forceinline__ bool title_time(const KeyWindow& k, uint64_t t0, uint
 }
 // Two steps, so that the lanes of a wave stay together: first the whole title by words, noting where "h=" and "e="
 // stand (up to four each, in order); then the candidates, every lane its first, its second, ...  The loads come in
-// batches -- four granules of the title at a time, one batch ahead; the windows of the first two candidates together --
+// batches -- kTG granules of the title at a time, one batch ahead (two: with four the kernel held 119 registers and four
+// waves per SIMD, with two 96 and five: 271 -> 261 us at 2 * 10^6 records; one spills); the windows of the first two
+// candidates together --
 // because the kernel is a chain of memory latencies and little else.
+constexpr int kTG = 2;
 __device__ __forceinline__ TitleFields parse_title(const uint8_t* __restrict__ text, uint64_t n, uint64_t a, uint64_t e) {
     TitleFields out{0, INT64_MIN, 0};
     if (e <= a + 1) return out;
@@ -482,20 +485,20 @@ __device__ __forceinline__ TitleFields parse_title(const uint8_t* __restrict__ t
         uintptr_t ga = base & ~(uintptr_t)15;
         int k = -(int)(base & 15u);           // index in the title of the granule's first byte
         uint32_t last_w = 0, any_cr = 0;      // the word in front of the one looked at; '\r' bytes seen
-        uint4 cur[4], nxt[4];
+        uint4 cur[kTG], nxt[kTG];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < kTG; ++i) {
             cur[i] = make_uint4(0, 0, 0, 0);
             if (ga + 16 * i < endp) cur[i] = *reinterpret_cast<const uint4*>(ga + 16 * i);
         }
         while (ga < endp) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < kTG; ++i) {
                 nxt[i] = make_uint4(0, 0, 0, 0);
-                if (ga + 64 + 16 * i < endp) nxt[i] = *reinterpret_cast<const uint4*>(ga + 64 + 16 * i);
+                if (ga + 16 * kTG + 16 * i < endp) nxt[i] = *reinterpret_cast<const uint4*>(ga + 16 * kTG + 16 * i);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < kTG; ++i) {
                 // the granule's bytes outside the title (the '@' at index 0 too) become zero: they match nothing
                 const int kg = k + 16 * i;
                 const int x0 = 1 - kg < 0 ? 0 : (1 - kg > 16 ? 16 : 1 - kg), x1 = len - kg < 0 ? 0 : (len - kg > 16 ? 16 : len - kg);
@@ -524,8 +527,8 @@ __device__ __forceinline__ TitleFields parse_title(const uint8_t* __restrict__ t
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
-            ga += 64; k += 64;
+            for (int i = 0; i < kTG; ++i) cur[i] = nxt[i];
+            ga += 16 * kTG; k += 16 * kTG;
         }
         if (any_cr)
             for (uint64_t p = a + 1; p < e; ++p) out.n_cr += text[p] == '\r';
@@ -627,7 +630,7 @@ __device__ __forceinline__ uint64_t f1_strip(const uint8_t* __restrict__ text, F
     return e - l.a;
 }
 
-__global__ __launch_bounds__(256) void fq1_finalize_kernel(const uint8_t* __restrict__ text, uint64_t n, uint64_t n_records,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void fq1_finalize_kernel(const uint8_t* __restrict__ text, uint64_t n, uint64_t n_records,
                                                            const uint64_t* __restrict__ points,
                                                            const Fq1Region* __restrict__ rb, uint64_t n_regions,
                                                            uint32_t cap_lines, uint64_t region_bytes, ReadArrays ra,
