@@ -4,7 +4,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collect
 seen=set()
 for r in csv.DictReader(open(f)):
     k=r['Kernel_Name'].split('(')[0]
-    if 'fq1' not in k: continue
+    if not any(w in k for w in (sys.argv[2:] or ['fq1'])): continue
     acc[k][r['Counter_Name']]+=float(r['Counter_Value'])
     if (k,r['Dispatch_Id']) not in seen: seen.add((k,r['Dispatch_Id'])); cnt[k]+=1
 for k in acc:
