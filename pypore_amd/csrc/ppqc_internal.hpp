@@ -335,7 +335,19 @@ __device__ __forceinline__ SegSums merged_sums(uint64_t a, uint64_t e, uint64_t 
     } else {
         Partial p = tail[ts];
         r.gcs = cnt_gcs(p.cnt); r.nn = cnt_n(p.cnt); r.qb = cnt_qb(p.cnt); r.hi = p.hi; r.lo = p.lo;
-        for (uint64_t t = ts + 1; t <= te; ++t) {
+        // (a read of megabases over 16 KiB tiles has a hundred of them: eight partials asked for at a time, not one
+        // memory latency each)
+        uint64_t t = ts + 1;
+        for (; t + 8 <= te + 1; t += 8) {
+            Partial q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = head[t + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                r.gcs += cnt_gcs(q[j].cnt); r.nn += cnt_n(q[j].cnt); r.qb += cnt_qb(q[j].cnt); r.hi += q[j].hi; r.lo += q[j].lo;
+            }
+        }
+        for (; t <= te; ++t) {
             p = head[t];
             r.gcs += cnt_gcs(p.cnt); r.nn += cnt_n(p.cnt); r.qb += cnt_qb(p.cnt); r.hi += p.hi; r.lo += p.lo;
         }
