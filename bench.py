@@ -44,6 +44,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the short end-to-end (pinned host -> GPU) leg")
     ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the config-3 sharded leg")
+    ap.add_argument("--merge-beside", action="store_true",
+                    help="A/B: the index-only merge collectives beside the per-read kernel on a side stream "
+                         "(finalize_distributed(early=True)) instead of all four behind it (the default: see there)")
     ap.add_argument("--config3-reads", type=int, default=0, help="reads of the config-3 job (0: the 10 M of BASELINE config 3)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="NOT a measurement: the N ranks share GPU 0 and talk over gloo, so that the whole N > 1 code path "
@@ -170,7 +173,17 @@ def workload_text(a, R, n_bytes):
 def timed_blocks(step, fence, steps, min_seconds, reduce_max):
     """Blocks of EXACTLY `steps` steps, each bracketed by fence() (barrier + synchronise) on both sides and reduced by
     MAX over the ranks; further blocks until `min_seconds` have been timed, decided on the reduced time so that every
-    rank runs the same number.  Returns (mean seconds per block, blocks, last tables)."""
+    rank runs the same number.  Returns (mean seconds per block, blocks, last tables).
+
+    The objects alive when the timing starts (torch, numpy, the workload) are moved out of the garbage collector's reach
+    first (gc.freeze): the collector stays on, but a collection that the step's own short-lived objects trigger then
+    looks at those only.  Without it the multi-GPU step -- six collectives, a few dozen tensors and views per step --
+    triggered a collection over everything torch had imported every fifth step, 1.3 ms of host time in front of the next
+    launch (measured: steps of 3.27, 3.27, 3.27, 4.55, 3.27 ms in every block); timeit switches the collector off for the
+    same reason."""
+    import gc
+    gc.collect()
+    gc.freeze()
     total, blocks, tables = 0.0, 0, None
     while True:
         fence()
@@ -274,7 +287,7 @@ def main():
         ctx.submit_device(R, n_bytes, d_bases.data_ptr(), d_quals.data_ptr(), d_off.data_ptr(), d_ch.data_ptr(),
                           d_mux.data_ptr(), d_t.data_ptr())
         if use_dist:
-            return finalize_distributed(ctx, dist, torch, copy=False)
+            return finalize_distributed(ctx, dist, torch, copy=False, early=True if a.merge_beside else None)
         return ctx.finalize(copy=False)   # tables delivered as views of the pinned host result buffer
 
     def fence():
@@ -388,7 +401,7 @@ def config3_sharded(a, torch, dist, qc, synth, finalize_distributed, dev, local,
         ctx.reset()
         ctx.submit_device(R, n_bytes, d_bases.data_ptr(), d_quals.data_ptr(), d_off.data_ptr(), d_ch.data_ptr(),
                           d_mux.data_ptr(), d_t.data_ptr())
-        return finalize_distributed(ctx, dist, torch, copy=False)
+        return finalize_distributed(ctx, dist, torch, copy=False, early=True if a.merge_beside else None)
 
     def fence():
         ctx.sync()

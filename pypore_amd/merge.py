@@ -6,8 +6,8 @@ collective; only the small integer tables are merged -- the counterpart of gathe
 the multiprocessing result queue in the reference (lib/seq_routines.py:940-942) and of the sum over channels in
 FastStats (lib/seq_routines.py:103-108):
 
-  beside the per-read kernel, on a side stream (everything here needs the CSR index only, which the batches left when
-  they were submitted):
+  with early=True beside the per-read kernel, on a side stream (everything here needs the CSR index only, which the
+  batches left when they were submitted):
   1. one all-reduce MAX on [max_len | chan_max_len | ~min_pos_len | ~chan_min_len] (a few KB; the device keeps the
      minima bitwise complemented so that they merge by MAX too)
   2. exact N50 by weighted radix select: three 2048-word histograms, each all-reduced between its histogram and its
@@ -17,8 +17,9 @@ FastStats (lib/seq_routines.py:103-108):
      not bucketed or pipelined -- and their copy to the host
   behind it:
   4. all-reduce SUM on the rest of the table buffer (histograms, per-hour and per-channel tables: a few thousand words)
-  (early=False, or a context that cannot tell its index-only results early: the same merges as four collectives behind
-  the kernel, the first select histogram fused into the table buffer's all-reduce)
+  (early=False, the default -- finalize_distributed says why --, or a context that cannot tell its index-only results
+  early: the same merges as four collectives behind the kernel, the first select histogram fused into the table buffer's
+  all-reduce)
 
 time_mode 1 (the reference's per-channel hour-wrap quirk, lib/fast5_reader.py:117-126) is defined on a channel's reads
 in start-time order, but it needs no reads in one place: the ranks agree on three small per-channel tables instead (the
@@ -88,6 +89,19 @@ def _merge_compat_counts(ctx, dist, torch, group):
 
 
 _SIDE = {}
+EARLY_DEFAULT = False   # finalize_distributed(early=None): see its docstring
+
+
+def _tensor(ctx, torch, views, name):
+    """torch tensor over one of the context's device tables, made once per context and table (the buffers do not move;
+    a finalize per step would otherwise build a dozen tensors and views every time)."""
+    cache = ctx.__dict__.setdefault("_dist_tensors", {})
+    ptr = views[name].__cuda_array_interface__["data"][0]
+    n = views[name].__cuda_array_interface__["shape"][0]
+    hit = cache.get(name)
+    if hit is None or hit[0] != (ptr, n):
+        hit = cache[name] = ((ptr, n), torch.as_tensor(views[name], device="cuda"))
+    return hit[1]
 
 
 def _side_stream(torch):
@@ -111,25 +125,43 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, 
     on every rank (the single-GPU algorithm; its sort grows with the whole job).  ``copy=False``: the tables are views
     of the context's pinned result buffer (``QCContext.fetch_tables``).
 
-    ``early`` (default: whenever the context says it can, ``QCContext.index_early`` -- every rank must take the same
-    path, and does when all ranks drive their contexts through the same calls): the extremes all-reduce and the three
+    ``early=True`` (the context must say it can, ``QCContext.index_early``, and every rank must take the same path --
+    which it does when all ranks drive their contexts through the same calls): the extremes all-reduce and the three
     select rounds depend on the CSR index only, which the batches left when they were submitted; they are issued on a
-    side stream and run WHILE the per-read kernel does, so that one collective (the table SUM) is left behind it."""
+    side stream, BESIDE the per-read kernel -- and so are the (channel, mux, hour) cells, all but a sliver of the table
+    buffer, their all-reduce and their copy to the host (``QCContext.cells_early``; not under
+    PPQC_COMPAT_MULTI_READ_SINGLE, which rewrites cells behind the tables) -- so that one collective over a few thousand
+    words (the histograms, the per-hour and per-channel tables) is left behind it.
+
+    The default is ``early=False`` -- four collectives behind the kernel -- because of what the side stream needs to be
+    worth anything ("Beside the kernel or behind it"; one rank over RCCL, config 2, same box): a kernel
+    launched beside ``tile_kernel`` at the same priority waits for hundreds of microseconds to be dispatched and then
+    crawls (the side chain 3.96 ms a step against 3.39 behind the kernel); on a high-priority stream the chain takes
+    0.3 ms beside the kernel and the step costs what the single-GPU step costs (3.28 ms) -- but streams of the highest
+    priority are what the stalls of this round had in common, and the first suite run with one stalled again; and with
+    HIP's default of four hardware queues the side stream of this module lands on the per-read stream's queue anyway,
+    where its six collectives run behind the kernel, two more than the four of the default."""
     handle = torch.cuda.current_stream().cuda_stream
     if ctx.external_stream != handle:
         ctx.set_stream(handle)
     if ctx.cfg.time_mode == 1:
         return _finalize_mode1(ctx, dist, torch, group, copy)
     if early is None:
-        early = n50 == "select" and ctx.index_early()
+        early = EARLY_DEFAULT and n50 == "select" and ctx.index_early()
     if early:
         side = _side_stream(torch)
         ctx.stream_wait_index(side.cuda_stream)
         views, _ = ctx.device_tables()
+        from ._lib import COMPAT_MULTI_READ_SINGLE
+        cells = not (ctx.cfg.compat_flags & COMPAT_MULTI_READ_SINGLE)
         with torch.cuda.stream(side):
-            t_maxmin = torch.as_tensor(views["maxmin"], device="cuda")
+            t_maxmin = _tensor(ctx, torch, views, "maxmin")
             _all_reduce(dist, torch, t_maxmin, dist.ReduceOp.MAX, group)
-            t_sel = torch.as_tensor(views["sel"], device="cuda")
+            if cells:
+                ctx.cells_early(0, side.cuda_stream)             # unpacked (or, past a packed cell's range, computed) behind side
+                _all_reduce(dist, torch, _tensor(ctx, torch, views, "cmh"), dist.ReduceOp.SUM, group)
+                ctx.cells_early(1, side.cuda_stream)             # the merged cells to the host result buffer, on side
+            t_sel = _tensor(ctx, torch, views, "sel")
             for r in range(3):
                 ctx.n50_select_early(r, 0, side.cuda_stream)
                 _all_reduce(dist, torch, t_sel, dist.ReduceOp.SUM, group)
@@ -138,19 +170,19 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, 
         ctx.finalize_extremes()
         _merge_compat_counts(ctx, dist, torch, group)
         ctx.finalize_tables()                    # uses the merged max_len; the N50 is final already
-        t_sum = torch.as_tensor(views["sum"], device="cuda")
+        t_sum = _tensor(ctx, torch, views, "small" if cells else "sum")
         _all_reduce(dist, torch, t_sum, dist.ReduceOp.SUM, group)
         return ctx.fetch_tables(copy=copy)
     ctx.finalize_extremes()
     views, _ = ctx.device_tables()
     # the device keeps the minima complemented, so maxima and minima merge in ONE all-reduce(MAX)
-    t_maxmin = torch.as_tensor(views["maxmin"], device="cuda")
+    t_maxmin = _tensor(ctx, torch, views, "maxmin")
     _all_reduce(dist, torch, t_maxmin, dist.ReduceOp.MAX, group)
     _merge_compat_counts(ctx, dist, torch, group)
     ctx.finalize_tables()                        # length histogram bins use the merged max_len
     if n50 == "select":
-        t_sum_sel = torch.as_tensor(views["sum_sel"], device="cuda")
-        t_sel = torch.as_tensor(views["sel"], device="cuda")
+        t_sum_sel = _tensor(ctx, torch, views, "sum_sel")
+        t_sel = _tensor(ctx, torch, views, "sel")
         ctx.n50_select_hist(0)
         _all_reduce(dist, torch, t_sum_sel, dist.ReduceOp.SUM, group)      # tables + first select histogram
         ctx.n50_select_pick(0)
@@ -159,11 +191,11 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, 
             _all_reduce(dist, torch, t_sel, dist.ReduceOp.SUM, group)
             ctx.n50_select_pick(r)
         return ctx.fetch_tables(copy=copy)
-    t_sum = torch.as_tensor(views["sum"], device="cuda")
+    t_sum = _tensor(ctx, torch, views, "sum")
     _all_reduce(dist, torch, t_sum, dist.ReduceOp.SUM, group)
     n_local = views["lengths"].__cuda_array_interface__["shape"][0]
     if n_local:
-        lens = torch.as_tensor(views["lengths"], device="cuda")
+        lens = _tensor(ctx, torch, views, "lengths")
     else:
         lens = torch.zeros(0, dtype=torch.int32, device="cuda")
     all_lens = gather_lengths(lens, dist, torch, group)
@@ -177,7 +209,7 @@ def _finalize_mode1(ctx, dist, torch, group, copy):
     histogram) -> SUM; two more select rounds.  Seven small collectives and one table-sized one, all stream-ordered."""
     ctx.finalize_extremes()
     views, _ = ctx.device_tables()
-    t_maxmin = torch.as_tensor(views["maxmin"], device="cuda")
+    t_maxmin = _tensor(ctx, torch, views, "maxmin")
     _all_reduce(dist, torch, t_maxmin, dist.ReduceOp.MAX, group)
     m1 = ctx.mode1_dist_tables()
     ctx.mode1_dist_phase(0)
@@ -188,8 +220,8 @@ def _finalize_mode1(ctx, dist, torch, group, copy):
     ctx.mode1_dist_phase(2)
     _merge_compat_counts(ctx, dist, torch, group)
     ctx.finalize_tables()
-    t_sum_sel = torch.as_tensor(views["sum_sel"], device="cuda")
-    t_sel = torch.as_tensor(views["sel"], device="cuda")
+    t_sum_sel = _tensor(ctx, torch, views, "sum_sel")
+    t_sel = _tensor(ctx, torch, views, "sel")
     ctx.n50_select_hist(0)
     _all_reduce(dist, torch, t_sum_sel, dist.ReduceOp.SUM, group)
     ctx.n50_select_pick(0)

@@ -53,6 +53,7 @@ class QCContext:
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
+        self.__dict__.pop("_dist_tensors", None)   # merge.py's tensors over the device tables (they point back at self)
         if getattr(self, "_ctx", None):
             self._lib.ppqc_destroy(self._ctx)
             self._ctx = None
