@@ -44,9 +44,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the short end-to-end (pinned host -> GPU) leg")
     ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the config-3 sharded leg")
-    ap.add_argument("--merge-beside", action="store_true",
-                    help="A/B: the index-only merge collectives beside the per-read kernel on a side stream "
-                         "(finalize_distributed(early=True)) instead of all four behind it (the default: see there)")
+    ap.add_argument("--merge-behind", action="store_true",
+                    help="A/B: the merge collectives behind the per-read kernel (finalize_distributed(early=False)) "
+                         "instead of beside it on a side stream")
     ap.add_argument("--config3-reads", type=int, default=0, help="reads of the config-3 job (0: the 10 M of BASELINE config 3)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="NOT a measurement: the N ranks share GPU 0 and talk over gloo, so that the whole N > 1 code path "
@@ -287,7 +287,7 @@ def main():
         ctx.submit_device(R, n_bytes, d_bases.data_ptr(), d_quals.data_ptr(), d_off.data_ptr(), d_ch.data_ptr(),
                           d_mux.data_ptr(), d_t.data_ptr())
         if use_dist:
-            return finalize_distributed(ctx, dist, torch, copy=False, early=True if a.merge_beside else None)
+            return finalize_distributed(ctx, dist, torch, copy=False, early=False if a.merge_behind else None)
         return ctx.finalize(copy=False)   # tables delivered as views of the pinned host result buffer
 
     def fence():
@@ -401,7 +401,7 @@ def config3_sharded(a, torch, dist, qc, synth, finalize_distributed, dev, local,
         ctx.reset()
         ctx.submit_device(R, n_bytes, d_bases.data_ptr(), d_quals.data_ptr(), d_off.data_ptr(), d_ch.data_ptr(),
                           d_mux.data_ptr(), d_t.data_ptr())
-        return finalize_distributed(ctx, dist, torch, copy=False, early=True if a.merge_beside else None)
+        return finalize_distributed(ctx, dist, torch, copy=False, early=False if a.merge_behind else None)
 
     def fence():
         ctx.sync()

@@ -6,8 +6,8 @@ collective; only the small integer tables are merged -- the counterpart of gathe
 the multiprocessing result queue in the reference (lib/seq_routines.py:940-942) and of the sum over channels in
 FastStats (lib/seq_routines.py:103-108):
 
-  with early=True beside the per-read kernel, on a side stream (everything here needs the CSR index only, which the
-  batches left when they were submitted):
+  beside the per-read kernel, on a side stream (everything here needs the CSR index only, which the batches left when
+  they were submitted):
   1. one all-reduce MAX on [max_len | chan_max_len | ~min_pos_len | ~chan_min_len] (a few KB; the device keeps the
      minima bitwise complemented so that they merge by MAX too)
   2. exact N50 by weighted radix select: three 2048-word histograms, each all-reduced between its histogram and its
@@ -17,9 +17,8 @@ FastStats (lib/seq_routines.py:103-108):
      not bucketed or pipelined -- and their copy to the host
   behind it:
   4. all-reduce SUM on the rest of the table buffer (histograms, per-hour and per-channel tables: a few thousand words)
-  (early=False, the default -- finalize_distributed says why --, or a context that cannot tell its index-only results
-  early: the same merges as four collectives behind the kernel, the first select histogram fused into the table buffer's
-  all-reduce)
+  (early=False, or a context that cannot tell its index-only results early: the same merges as four collectives behind
+  the kernel, the first select histogram fused into the table buffer's all-reduce)
 
 time_mode 1 (the reference's per-channel hour-wrap quirk, lib/fast5_reader.py:117-126) is defined on a channel's reads
 in start-time order, but it needs no reads in one place: the ranks agree on three small per-channel tables instead (the
@@ -88,8 +87,59 @@ def _merge_compat_counts(ctx, dist, torch, group):
         _all_reduce(dist, torch, torch.as_tensor(ctx.compat_dist_count(), device="cuda"), dist.ReduceOp.SUM, group)
 
 
-_SIDE = {}
-EARLY_DEFAULT = False   # finalize_distributed(early=None): see its docstring
+EARLY_DEFAULT = True    # finalize_distributed(early=None): beside the per-read kernel whenever the context can
+CELLS_BESIDE = True     # ... and in the flow behind the kernel, the cells alone still go beside it
+_BESIDE = {}
+
+
+def _beside_stream(torch):
+    """A stream whose work really runs beside the current stream's.  HIP maps its streams onto a few hardware queues
+    (GPU_MAX_HW_QUEUES, four by default), and two streams on one queue run in submission order whatever their events
+    allow: a side stream that shared the per-read stream's queue ran its whole chain BEHIND the per-read kernel (six
+    collectives in the step's tail instead of one), and the 13.8 MB copy of config 3's cells sat in front of the select
+    rounds it was meant to run beside.  Which streams share depends on everything the process has created, so it is
+    measured, once per device, thread and current stream: a short sleep on the current stream, an event on a candidate;
+    the first of a few fresh streams whose event does not wait for the sleep is kept.  On such a stream kernels launched
+    beside ``tile_kernel`` start at once (17-40 us each); no priority is asked for (a high-priority stream gave the same
+    timeline, and stalled the suite: DESIGN section 5)."""
+    import threading
+    cur = torch.cuda.current_stream()
+    key = (torch.cuda.current_device(), threading.get_ident(), cur.cuda_stream)
+    if key in _BESIDE:
+        return _BESIDE[key]
+    chosen = None
+    for _ in range(6):
+        cand = torch.cuda.Stream(device=key[0])
+        t0, t_cur, t_cand = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        cur.synchronize()
+        cand.synchronize()
+        t0.record(cur)
+        torch.cuda._sleep(400_000)             # on the current stream: a fraction of a millisecond to a few
+        t_cur.record(cur)
+        cand.wait_event(t0)
+        t_cand.record(cand)
+        cur.synchronize()
+        cand.synchronize()
+        if chosen is None:
+            chosen = cand
+        if t0.elapsed_time(t_cand) < 0.5 * t0.elapsed_time(t_cur):
+            chosen = cand
+            break
+    _BESIDE[key] = chosen
+    return chosen
+
+
+def _cells_to_host(ctx, torch):
+    """The (channel, mux, hour) cells -- all but a sliver of the table buffer, 13.8 MB at 3000 x 4 x 72 -- to the host result
+    buffer on the side stream, as soon as the current stream has merged them: beside what is still to come on that stream
+    (select rounds, a gather and sort), and the fetch at the end copies the small tables only.  (Not under
+    PPQC_COMPAT_MULTI_READ_SINGLE: QCContext.cells_early refuses there.)"""
+    from ._lib import COMPAT_MULTI_READ_SINGLE
+    if ctx.cfg.compat_flags & COMPAT_MULTI_READ_SINGLE:
+        return
+    cs = _beside_stream(torch)
+    cs.wait_stream(torch.cuda.current_stream())
+    ctx.cells_early(1, cs.cuda_stream)
 
 
 def _tensor(ctx, torch, views, name):
@@ -104,15 +154,6 @@ def _tensor(ctx, torch, views, name):
     return hit[1]
 
 
-def _side_stream(torch):
-    """One extra stream per device and driving thread for the merges that run beside the per-read kernel."""
-    import threading
-    key = (torch.cuda.current_device(), threading.get_ident())
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=key[0])
-    return _SIDE[key]
-
-
 def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, early=None):
     """Phased finalize of a QCContext with RCCL merges in between; returns the merged tables on every rank.
 
@@ -125,22 +166,16 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, 
     on every rank (the single-GPU algorithm; its sort grows with the whole job).  ``copy=False``: the tables are views
     of the context's pinned result buffer (``QCContext.fetch_tables``).
 
-    ``early=True`` (the context must say it can, ``QCContext.index_early``, and every rank must take the same path --
-    which it does when all ranks drive their contexts through the same calls): the extremes all-reduce and the three
+    ``early`` (default: whenever the context says it can, ``QCContext.index_early`` -- every rank must take the same
+    path, and does when all ranks drive their contexts through the same calls): the extremes all-reduce and the three
     select rounds depend on the CSR index only, which the batches left when they were submitted; they are issued on a
     side stream, BESIDE the per-read kernel -- and so are the (channel, mux, hour) cells, all but a sliver of the table
     buffer, their all-reduce and their copy to the host (``QCContext.cells_early``; not under
     PPQC_COMPAT_MULTI_READ_SINGLE, which rewrites cells behind the tables) -- so that one collective over a few thousand
-    words (the histograms, the per-hour and per-channel tables) is left behind it.
-
-    The default is ``early=False`` -- four collectives behind the kernel -- because of what the side stream needs to be
-    worth anything ("Beside the kernel or behind it"; one rank over RCCL, config 2, same box): a kernel
-    launched beside ``tile_kernel`` at the same priority waits for hundreds of microseconds to be dispatched and then
-    crawls (the side chain 3.96 ms a step against 3.39 behind the kernel); on a high-priority stream the chain takes
-    0.3 ms beside the kernel and the step costs what the single-GPU step costs (3.28 ms) -- but streams of the highest
-    priority are what the stalls of this round had in common, and the first suite run with one stalled again; and with
-    HIP's default of four hardware queues the side stream of this module lands on the per-read stream's queue anyway,
-    where its six collectives run behind the kernel, two more than the four of the default."""
+    words (the histograms, the per-hour and per-channel tables) is left behind it.  What that takes of the side stream
+    -- a hardware queue it does not share with the per-read stream, found by a probe, and no priority -- is in
+    ``_beside_stream`` and in DESIGN section 5, "Beside the kernel or behind it".  ``early=False``: four collectives
+    behind the kernel, with the cells alone still merged and copied beside it where the context can say so."""
     handle = torch.cuda.current_stream().cuda_stream
     if ctx.external_stream != handle:
         ctx.set_stream(handle)
@@ -149,7 +184,7 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, 
     if early is None:
         early = EARLY_DEFAULT and n50 == "select" and ctx.index_early()
     if early:
-        side = _side_stream(torch)
+        side = _beside_stream(torch)
         ctx.stream_wait_index(side.cuda_stream)
         views, _ = ctx.device_tables()
         from ._lib import COMPAT_MULTI_READ_SINGLE
@@ -173,8 +208,20 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, 
         t_sum = _tensor(ctx, torch, views, "small" if cells else "sum")
         _all_reduce(dist, torch, t_sum, dist.ReduceOp.SUM, group)
         return ctx.fetch_tables(copy=copy)
-    ctx.finalize_extremes()
+    from ._lib import COMPAT_MULTI_READ_SINGLE
+    cells_beside = (CELLS_BESIDE and n50 == "select" and not (ctx.cfg.compat_flags & COMPAT_MULTI_READ_SINGLE)
+                    and ctx.index_early())
     views, _ = ctx.device_tables()
+    if cells_beside:
+        # the cells alone beside the per-read kernel (three launches on a stream of another hardware queue: slow there,
+        # but done long before that kernel is): unpack, all-reduce, copy to the host
+        cs = _beside_stream(torch)
+        ctx.stream_wait_index(cs.cuda_stream)
+        with torch.cuda.stream(cs):
+            ctx.cells_early(0, cs.cuda_stream)
+            _all_reduce(dist, torch, _tensor(ctx, torch, views, "cmh"), dist.ReduceOp.SUM, group)
+            ctx.cells_early(1, cs.cuda_stream)
+    ctx.finalize_extremes()
     # the device keeps the minima complemented, so maxima and minima merge in ONE all-reduce(MAX)
     t_maxmin = _tensor(ctx, torch, views, "maxmin")
     _all_reduce(dist, torch, t_maxmin, dist.ReduceOp.MAX, group)
@@ -184,7 +231,12 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, 
         t_sum_sel = _tensor(ctx, torch, views, "sum_sel")
         t_sel = _tensor(ctx, torch, views, "sel")
         ctx.n50_select_hist(0)
-        _all_reduce(dist, torch, t_sum_sel, dist.ReduceOp.SUM, group)      # tables + first select histogram
+        if cells_beside:
+            _all_reduce(dist, torch, _tensor(ctx, torch, views, "small"), dist.ReduceOp.SUM, group)
+            _all_reduce(dist, torch, t_sel, dist.ReduceOp.SUM, group)
+        else:
+            _all_reduce(dist, torch, t_sum_sel, dist.ReduceOp.SUM, group)  # tables + first select histogram
+            _cells_to_host(ctx, torch)           # the merged cells are final: their copy beside the last two rounds
         ctx.n50_select_pick(0)
         for r in (1, 2):
             ctx.n50_select_hist(r)
@@ -193,6 +245,7 @@ def finalize_distributed(ctx, dist, torch, group=None, n50="select", copy=True, 
         return ctx.fetch_tables(copy=copy)
     t_sum = _tensor(ctx, torch, views, "sum")
     _all_reduce(dist, torch, t_sum, dist.ReduceOp.SUM, group)
+    _cells_to_host(ctx, torch)
     n_local = views["lengths"].__cuda_array_interface__["shape"][0]
     if n_local:
         lens = _tensor(ctx, torch, views, "lengths")

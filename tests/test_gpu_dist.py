@@ -31,7 +31,7 @@ def test_finalize_distributed_one_rank_nccl_and_zero_copy_views(c_oracle):
         b = random_batch(5, 20000, 300, n_channels=3000, hours=75)
         with qc.QCContext(device=0, **cfg) as ctx:
             ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], b["fail_flag"])
-            merged = finalize_distributed(ctx, dist, torch, early=True)      # the merges beside the per-read kernel
+            merged = finalize_distributed(ctx, dist, torch)                  # the merges beside the per-read kernel (default)
             assert ctx.external_stream == torch.cuda.current_stream().cuda_stream
             assert ctx.index_early() is False                                # consumed by the finalize
             ctx.reset()
@@ -40,7 +40,7 @@ def test_finalize_distributed_one_rank_nccl_and_zero_copy_views(c_oracle):
             phased = finalize_distributed(ctx, dist, torch, early=False)     # four collectives behind the kernel
             assert_tables_equal(merged, phased, "early vs phased merge")
             ctx.reset()                                                      # an empty shard takes the early path too
-            empty = finalize_distributed(ctx, dist, torch, early=True)
+            empty = finalize_distributed(ctx, dist, torch)
             assert empty["totals"].sum() == 0 and empty["n50"] == 0 and empty["max_len"] == 0
             ctx.reset()
             ctx.submit(b["bases"], b["quals"], b["offsets"], b["channel"], b["mux"], b["time"], b["fail_flag"])
@@ -195,7 +195,7 @@ def _submit_shard(torch, ctx, job, a, e, keep):
                           job["d_ch"].data_ptr() + 4 * a, job["d_mux"].data_ptr() + a, job["d_t"].data_ptr() + 8 * a)
 
 
-FLOWS = (("early", 0, dict(early=True)), ("phased", 0, {}), ("gather", 0, dict(n50="gather")), ("time_mode 1", 1, {}))
+FLOWS = (("early", 0, {}), ("phased", 0, dict(early=False)), ("gather", 0, dict(n50="gather")), ("time_mode 1", 1, {}))
 SLEEP_CYCLES = 40_000_000     # torch.cuda._sleep: the stream is held while the host enqueues the whole chain behind it
 
 
@@ -268,7 +268,8 @@ def test_every_collective_finds_its_producers_in_stream_order():
                     assert same and n >= 2 and not bad, \
                         "%s (own stream %s): collectives %s of %d found tensors their producers had not finished" % (
                             label, own_stream, bad, n)
-                    assert len(streams) == (2 if label == "early" else 1)   # early: side-stream collectives + the table SUM
+                    # early: side-stream collectives + the table SUM; phased: the cells' all-reduce on its own stream
+                    assert len(streams) == (2 if label in ("early", "phased") else 1)
         keep = qc.QCContext.stream_wait_index
         qc.QCContext.stream_wait_index = lambda self, handle: None          # negative control: a wait that is missing
         # (HIP maps its streams onto a few hardware queues -- GPU_MAX_HW_QUEUES, four here -- and two streams that share
@@ -276,13 +277,14 @@ def test_every_collective_finds_its_producers_in_stream_order():
         # stream, or of the context's auxiliary stream with the index kernel waiting on it, finds its producers finished by
         # accident, and no check from outside can tell.  Which streams share depends on everything the process has created
         # so far (seen: blind after a time_mode 1 context had passed its streams on), so the control is run with a fresh
-        # side stream and a fresh stream to hold until one pair does not share.)
+        # side stream (merge._beside_stream probes again, among fresh streams) and a fresh stream to hold until one pair
+        # does not share.)
         from pypore_amd import merge
         tried = []
-        side_kept = dict(merge._SIDE)
+        side_kept = dict(merge._BESIDE)
         try:
             for _ in range(6):
-                merge._SIDE.clear()
+                merge._BESIDE.clear()
                 with torch.cuda.stream(torch.cuda.Stream()):
                     same, n, bad, _ = _snapshot_flow(torch, dist, *FLOWS[0])
                 tried.append(bad)
@@ -290,8 +292,8 @@ def test_every_collective_finds_its_producers_in_stream_order():
                     break
         finally:
             qc.QCContext.stream_wait_index = keep
-            merge._SIDE.clear()
-            merge._SIDE.update(side_kept)
+            merge._BESIDE.clear()
+            merge._BESIDE.update(side_kept)
         assert tried[-1] and 0 in tried[-1], "the snapshot check did not notice a missing wait (%s of %d)" % (tried, n)
     finally:
         dist.destroy_process_group()

@@ -49,7 +49,7 @@ all_lens = np.concatenate([np.where((bb["channel"] >= 1) & (bb["channel"] <= 512
                                     np.diff(bb["offsets"].astype(np.int64)), 0) for bb in batches])
 want_n50 = co.n50(all_lens.astype(np.uint32))
 with qc.QCContext(device=0, **cfg) as ctx:
-    for label, kw in (("early", dict(early=True)), ("phased", {}), ("gather", dict(n50="gather"))):
+    for label, kw in (("early", {}), ("phased", dict(early=False)), ("gather", dict(n50="gather"))):
         ctx.reset()
         submit(ctx, b)
         got = finalize_distributed(ctx, dist, torch, **kw)
@@ -61,7 +61,7 @@ with qc.QCContext(device=0, **cfg) as ctx:
     if rank == 0:
         submit(ctx, b)
     assert ctx.index_early()
-    got = finalize_distributed(ctx, dist, torch, early=True)
+    got = finalize_distributed(ctx, dist, torch)
     assert_tables_equal(got, singles[0], "empty shard")
 # time_mode 1 with every channel's reads on both ranks: ONE batch cut in two contiguous halves (channels are random over
 # the reads), merged tables against one context over the whole batch (the sort-based hours) -- and an empty shard

@@ -54,7 +54,7 @@ for i in range(N + 10):
     if mode == "plain":
         ctx.finalize(copy=False)
     else:
-        finalize_distributed(ctx, dist, torch, copy=False, early=mode == "early")
+        finalize_distributed(ctx, dist, torch, copy=False, early=None if mode == "early" else False)
     t3 = time.perf_counter()
     acc += (t1 - t0, t2 - t1, t3 - t2, (t_fetch[0] - t2) if mode != "plain" else 0.0)
 step = (time.perf_counter() - t_all) / N * 1e3
