@@ -299,6 +299,39 @@ def test_every_collective_finds_its_producers_in_stream_order():
         dist.destroy_process_group()
 
 
+def test_the_side_stream_runs_beside_the_current_one():
+    """merge._beside_stream: the stream the merges beside the per-read kernel are issued on must not share the current
+    stream's hardware queue (HIP maps streams onto a few; two streams on one queue run in submission order).  Holds the
+    current stream with a sleep kernel and checks that an event on the chosen stream completes long before the sleep
+    does -- on torch's default stream and on fresh ones, after the process has created a few dozen other streams."""
+    import torch
+    from pypore_amd import merge
+    torch.cuda.set_device(0)
+    junk = [torch.cuda.Stream() for _ in range(24)]     # whatever else a process may have created
+    kept = dict(merge._BESIDE)
+    try:
+        for own in (False, True, True):
+            with torch.cuda.stream(torch.cuda.Stream() if own else torch.cuda.current_stream()):
+                merge._BESIDE.clear()
+                cur = torch.cuda.current_stream()
+                side = merge._beside_stream(torch)
+                assert side.cuda_stream != cur.cuda_stream and merge._beside_stream(torch) is side   # probed once
+                t0, t_cur, t_side = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                torch.cuda.synchronize()
+                t0.record(cur)
+                torch.cuda._sleep(2_000_000)
+                t_cur.record(cur)
+                side.wait_event(t0)
+                t_side.record(side)
+                torch.cuda.synchronize()
+                held, beside = t0.elapsed_time(t_cur), t0.elapsed_time(t_side)
+                assert beside < 0.25 * held, "the side stream waited for the held stream: %.3f of %.3f ms" % (beside, held)
+    finally:
+        merge._BESIDE.clear()
+        merge._BESIDE.update(kept)
+    del junk
+
+
 def test_two_ranks_in_one_process_stream_ordered(c_oracle):
     """world_size 2 with no host drain anywhere: two threads drive one context each on streams of their own, and the
     collectives between them are carried out in stream order on a communication stream (LocalStreamWorld), with each
