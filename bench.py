@@ -265,6 +265,8 @@ def main():
     ctx = qc.QCContext(device=local, **cfg)
     if use_dist:   # one stream-ordered chain of kernels and RCCL collectives, no host synchronisation in a step
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        from pypore_amd.merge import _beside_stream
+        _beside_stream(torch)   # the side stream's probe (a few sleeps of a millisecond) belongs to the set-up, not to a step
 
     # inputs resident in HBM before the timed region
     d_bases = torch.empty(n_bytes + 64, dtype=torch.uint8, device=dev)
@@ -386,6 +388,8 @@ def config3_sharded(a, torch, dist, qc, synth, finalize_distributed, dev, local,
                tz_offset_s=0, ref_time_s=1_528_000_000, fail_q=7.0, max_reads_hint=R)
     ctx = qc.QCContext(device=local, **cfg)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    from pypore_amd.merge import _beside_stream
+    _beside_stream(torch)       # (set-up, as in the headline leg)
     # byte i of the job's streams depends on (seed, i) alone, so the shard's bytes are generated in place from b0 on
     d_bases = torch.empty(n_bytes + 64, dtype=torch.uint8, device=dev)
     d_quals = torch.empty(n_bytes + 64, dtype=torch.uint8, device=dev)
